@@ -1,0 +1,82 @@
+/*
+ * spleeterrt_amd.h — device-resident C ABI of the MI355X separation engine (libspleeterrt_amd.so).
+ *
+ * Plain C, no torch / HIP types in the signatures: `stream` is a hipStream_t passed as void*, every `d_*`
+ * pointer is a device (HBM) address, every `h_*` pointer is host memory.  All functions return 0 on success
+ * and a negative code on failure (srtLastError() gives the text); nothing here ever falls back to a CPU path.
+ *
+ * This is the batched, HBM-resident form of the reference's per-tile calls.  What each entry point replaces
+ * (file:line under the reference tree):
+ *   srtCreate / srtDestroy      allocateSpleeterStr + initSpleeter + freeSpleeter   Executable/spleeter.c:111-176,310-320
+ *                               and InitSTFT / FreeSTFT                             Executable/stftFix.c:302-362
+ *   srtSetCoeff*                the borrowed `coeff` argument of initSpleeter        Executable/spleeter.c:129
+ *                               / lib2stem_loadCoefficients (fp16 container)         Executable/main.c:423-443
+ *   srtForward                  processSpleeter for nstems x ntiles tiles at once    Executable/spleeter.c:177-301
+ *   srtStft                     stft + the magnitude loop of processMT               Executable/stftFix.c:363-495, main.c:462-471
+ *   srtIstft                    the mask loop of processMT + istft                   Executable/main.c:473-494, stftFix.c:496-579
+ *   srtSeparate                 main()'s stft -> processMT -> istft sequence         Executable/main.c:776-785
+ * The drop-in, host-pointer forms with the reference's exact signatures are in spleeter.h / stftFix.h.
+ */
+#ifndef SPLEETERRT_AMD_H
+#define SPLEETERRT_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_API __attribute__((visibility("default")))
+#define SRT_MAX_STEMS 8
+#define SRT_VARIANT_EXE 0   /* LUT sigmoid + ELU clamp  (Executable/spleeter.c:29-56) */
+#define SRT_VARIANT_VST 1   /* exact sigmoid, plain ELU (VST/Source/spleeter.c:56-77) */
+#define SRT_IMPL_MFMA   0   /* MFMA implicit-GEMM kernels (product path) */
+#define SRT_IMPL_NAIVE  1   /* one-thread-per-output HIP kernels (debug cross-check, still GPU) */
+
+typedef struct srt_engine srt_engine;
+
+typedef struct srt_config {
+    int   F;                        /* analyseBinLimit: tile width in bins, multiple of 64, <= 2048   main.c:701 */
+    int   T;                        /* timeStep: tile height in frames, multiple of 64                main.c:702 */
+    int   n_stems;                  /* sub-networks evaluated per tile, 1..SRT_MAX_STEMS */
+    int   stem_mode[SRT_MAX_STEMS]; /* 0: LeakyReLU/ReLU, !=0: ELU/ELU                                spleeter.c:130-139 */
+    float oob_weight[SRT_MAX_STEMS];/* weight of bins F..2048 ("unaffectedWeight" = 0.1)              main.c:773 */
+    int   variant;                  /* SRT_VARIANT_* */
+    int   max_tiles;                /* capacity: tiles per batch */
+    int   impl;                     /* SRT_IMPL_* */
+} srt_config;
+
+SRT_API int  srtCreate(const srt_config *cfg, void *stream, srt_engine **out);
+SRT_API void srtDestroy(srt_engine *e);
+SRT_API const char *srtLastError(void);
+SRT_API size_t srtCoeffBytes(void);                                           /* == getCoeffSize() == 39 290 900 */
+
+/* weights for one sub-network, layout of spleeterCoeff (spleeter.h).  The data is copied; nothing is borrowed. */
+SRT_API int  srtSetCoeffHost(srt_engine *e, int stem, const void *h_coeff);
+SRT_API int  srtSetCoeffDevice(srt_engine *e, int stem, const void *d_coeff);
+SRT_API int  srtSetCoeffFp16Host(srt_engine *e, int stem, const uint16_t *h_halfs);   /* spleeterQuantizedSubNet */
+
+/* d_mag: [ntiles][2][T][F] magnitudes; d_masks: [n_stems][ntiles][2][T][F] */
+SRT_API int  srtForward(srt_engine *e, const float *d_mag, int ntiles, float *d_masks);
+
+/* geometry helpers for an n-sample stereo signal (n >= 4096) */
+SRT_API size_t srtStftRows(size_t n);            /* ceil(n/1024): rows the reference allocates          stftFix.c:367 */
+SRT_API size_t srtStftFrames(size_t n);          /* rows that actually receive a transform              stftFix.c:378 */
+SRT_API size_t srtIstftLength(size_t rows);      /* rows*1024 + 3072                                    stftFix.c:500 */
+
+/* STFT of planar stereo PCM resident in HBM.  d_spec: [2][rows][2052] interleaved (re,im) with the reference's
+ * conjugate convention; rows = srtStftRows(n).  d_mag (optional, may be NULL): [ceil(rows/T)][2][T][F]. */
+SRT_API int  srtStft(srt_engine *e, const float *d_L, const float *d_R, size_t n, float *d_spec, float *d_mag);
+/* d_masks: [n_stems][ntiles][2][T][F] (NULL = all-ones).  d_out: [n_stems][2][srtIstftLength(rows)] */
+SRT_API int  srtIstft(srt_engine *e, const float *d_spec, size_t rows, const float *d_masks, float *d_out);
+/* whole hot path, everything in HBM: PCM -> STFT -> |.| -> U-Nets -> mask -> iSTFT.  d_out as in srtIstft. */
+SRT_API int  srtSeparate(srt_engine *e, const float *d_L, const float *d_R, size_t n, float *d_out);
+
+/* debug / measurement */
+SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */
+SRT_API int  srtSetTiming(srt_engine *e, int enable);                    /* record HIP events around every launch of the next calls */
+SRT_API int  srtGetTiming(srt_engine *e, char *names, size_t names_bytes, float *ms, int max_entries); /* returns count; syncs the stream */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,182 @@
+"""ctypes binding of include/spleeterrt_amd.h.  Fails loudly if the HIP library is missing — there is no CPU path."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(PKG, "libspleeterrt_amd.so")
+MAX_STEMS = 8
+VARIANT_EXE, VARIANT_VST = 0, 1
+IMPL_MFMA, IMPL_NAIVE = 0, 1
+COEFF_FLOATS = 9822725
+SPEC_LD = 2052
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("F", C.c_int), ("T", C.c_int), ("n_stems", C.c_int), ("stem_mode", C.c_int * MAX_STEMS),
+                ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libspleeterrt_amd.so.  torch is imported first so both share one HIP runtime (same SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise EngineError("%s not built: run `python -m spleeterrt_amd.build` (needs hipcc); no CPU fallback exists" % SO)
+    import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
+    L = C.CDLL(SO)
+    vp, f32p = C.c_void_p, C.c_void_p
+    L.srtCreate.argtypes = [C.POINTER(_Config), vp, C.POINTER(vp)]
+    L.srtDestroy.argtypes = [vp]
+    L.srtDestroy.restype = None
+    L.srtLastError.restype = C.c_char_p
+    L.srtCoeffBytes.restype = C.c_size_t
+    L.srtSetCoeffHost.argtypes = [vp, C.c_int, vp]
+    L.srtSetCoeffDevice.argtypes = [vp, C.c_int, vp]
+    L.srtSetCoeffFp16Host.argtypes = [vp, C.c_int, vp]
+    L.srtForward.argtypes = [vp, f32p, C.c_int, f32p]
+    for fn in (L.srtStftRows, L.srtStftFrames, L.srtIstftLength):
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_size_t]
+    L.srtStft.argtypes = [vp, f32p, f32p, C.c_size_t, f32p, f32p]
+    L.srtIstft.argtypes = [vp, f32p, C.c_size_t, f32p, f32p]
+    L.srtSeparate.argtypes = [vp, f32p, f32p, C.c_size_t, f32p]
+    L.srtCopyTensor.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
+    L.srtSetTiming.argtypes = [vp, C.c_int]
+    L.srtGetTiming.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
+    _lib = L
+    return L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One engine per (device, stream): nstems sub-networks evaluated over batches of T x F spectrogram tiles."""
+
+    def __init__(self, F=1024, T=256, stem_modes=(1, 1, 1, 1), oob_weights=None, variant=VARIANT_EXE, max_tiles=1,
+                 impl=IMPL_MFMA, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: spleeterrt_amd has no CPU path")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.L = load_library()
+        self.F, self.T, self.S, self.max_tiles, self.variant = F, T, len(stem_modes), max_tiles, variant
+        cfg = _Config()
+        cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.impl = F, T, self.S, variant, max_tiles, impl
+        for i, m in enumerate(stem_modes):
+            cfg.stem_mode[i] = int(m)
+            cfg.oob_weight[i] = 0.1 if oob_weights is None else float(oob_weights[i])
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        self._chk(self.L.srtCreate(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise EngineError("libspleeterrt_amd: %s (rc=%d)" % (self.L.srtLastError().decode(), rc))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.srtDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def set_coeff(self, stem, coeff):
+        """coeff: numpy float32[9822725] (host) or a CUDA float32 tensor (device), spleeterCoeff layout."""
+        import numpy as np
+        if isinstance(coeff, np.ndarray):
+            a = np.ascontiguousarray(coeff, np.float32)
+            assert a.size == COEFF_FLOATS
+            self._chk(self.L.srtSetCoeffHost(self.h, stem, C.c_void_p(a.ctypes.data)))
+        else:
+            assert coeff.is_cuda and coeff.numel() == COEFF_FLOATS and coeff.dtype == self.torch.float32
+            self._chk(self.L.srtSetCoeffDevice(self.h, stem, _ptr(coeff.contiguous())))
+
+    def set_coeff_fp16(self, stem, halfs):
+        import numpy as np
+        a = np.ascontiguousarray(halfs, np.uint16)
+        assert a.size == COEFF_FLOATS
+        self._chk(self.L.srtSetCoeffFp16Host(self.h, stem, C.c_void_p(a.ctypes.data)))
+
+    # ---- stages (all tensors live on self.device)
+    def forward(self, mag, masks=None):
+        """mag [ntiles,2,T,F] -> masks [S,ntiles,2,T,F]"""
+        t = self.torch
+        nt = mag.shape[0]
+        assert mag.is_cuda and mag.dtype == t.float32 and tuple(mag.shape[1:]) == (2, self.T, self.F)
+        mag = mag.contiguous()
+        if masks is None:
+            masks = t.empty((self.S, nt, 2, self.T, self.F), device=self.device, dtype=t.float32)
+        self._chk(self.L.srtForward(self.h, _ptr(mag), nt, _ptr(masks)))
+        return masks
+
+    def stft(self, L, R, want_mag=True):
+        """planar PCM -> (spec [2,rows,2052,2], mag [ntiles,2,T,F] or None)"""
+        t = self.torch
+        n = L.numel()
+        rows = self.L.srtStftRows(n)
+        nt = (rows + self.T - 1) // self.T
+        spec = t.empty((2, rows, SPEC_LD, 2), device=self.device, dtype=t.float32)
+        mag = t.empty((nt, 2, self.T, self.F), device=self.device, dtype=t.float32) if want_mag else None
+        self._chk(self.L.srtStft(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, _ptr(spec), _ptr(mag)))
+        return spec, mag
+
+    def istft(self, spec, masks=None):
+        """spec [2,rows,2052,2], masks [S,ntiles,2,T,F] or None -> out [S,2,rows*1024+3072]"""
+        t = self.torch
+        rows = spec.shape[1]
+        out = t.empty((self.S, 2, self.L.srtIstftLength(rows)), device=self.device, dtype=t.float32)
+        self._chk(self.L.srtIstft(self.h, _ptr(spec), rows, _ptr(masks), _ptr(out)))
+        return out
+
+    def separate(self, L, R, out=None):
+        """whole path: planar PCM [n] x2 -> stems [S,2,rows*1024+3072]"""
+        t = self.torch
+        n = L.numel()
+        rows = self.L.srtStftRows(n)
+        if out is None:
+            out = t.empty((self.S, 2, self.L.srtIstftLength(rows)), device=self.device, dtype=t.float32)
+        self._chk(self.L.srtSeparate(self.h, _ptr(L), _ptr(R), n, _ptr(out)))
+        return out
+
+    # ---- debug / measurement
+    def tensor(self, name, stem, tile):
+        import numpy as np
+        lvl = int(name[-1])
+        if name.startswith("up"):
+            co = (256, 128, 64, 32, 16, 1)[lvl - 1]
+            sh = (co, self.T >> (6 - lvl), self.F >> (6 - lvl))
+        else:
+            co = (16, 32, 64, 128, 256, 512)[lvl - 1]
+            sh = (co, self.T >> lvl, self.F >> lvl)
+        a = np.empty(sh, np.float32)
+        self._chk(self.L.srtCopyTensor(self.h, name.encode(), stem, tile, C.c_void_p(a.ctypes.data), a.size))
+        return a
+
+    def set_timing(self, on=True):
+        self._chk(self.L.srtSetTiming(self.h, int(on)))
+
+    def get_timing(self, max_entries=65536):
+        names = C.create_string_buffer(max_entries * 8)
+        ms = (C.c_float * max_entries)()
+        n = self._chk(self.L.srtGetTiming(self.h, names, len(names), ms, max_entries))
+        nm = names.value.decode().split(",")[:n]
+        return list(zip(nm, list(ms[:n])))

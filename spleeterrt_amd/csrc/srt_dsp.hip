@@ -1,0 +1,243 @@
+// srt_dsp.hip — STFT / magnitude / mask-apply / inverse STFT / overlap-add kernels for gfx950.
+//
+// Replaces, for the hot path only:
+//   stft    : Executable/stftFix.c:363-495 (window, bit-reverse, DFT4096 x2, re/im unpack)      K1
+//   mag     : Executable/main.c:462-471, :500-514                                              K2
+//   mask    : Executable/main.c:473-494                                                        K8
+//   istft   : Executable/stftFix.c:496-579 (Hartley pack, DFT4096, post-window, overlap-add)   K9
+//   DFT4096 : Executable/codelet.c:2-271  (4096-point fast Hartley transform)
+//
+// Design (not a translation of the Hartley codelet): one 256-thread workgroup runs a 4096-point COMPLEX FFT
+// entirely in registers + LDS as three radix-16 passes (16 values per thread).  Left and right channels ride in
+// the real and imaginary parts of the same transform (z = L + iR), so one FFT serves both channels of a frame;
+// the two spectra are separated in the epilogue, where the magnitude tile for the network is emitted as well.
+// The inverse uses the same FFT (swap trick) on G = F'_L + i F'_R after the per-stem mask multiply, so the
+// spectrum row is read once for all stems.  Overlap-add is a deterministic 4-frame gather in frame order.
+#include "srt_internal.h"
+
+#define FFT_EX1_LD 272      // exchange-1 row stride (float2): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
+#define FFT_EX2_LD 257      // exchange-2 row stride (float2): odd -> conflict-free strided b64 writes
+#define FFT_SMEM_F2 4352    // 16*272 float2 scratch (also holds 4096 natural-order points)
+
+__device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return f2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// forward 4-point DFT in place (W4 = -i)
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d)
+{
+    const float2 s0 = f2(a.x + c.x, a.y + c.y), s1 = f2(a.x - c.x, a.y - c.y);
+    const float2 s2 = f2(b.x + d.x, b.y + d.y), s3 = f2(b.x - d.x, b.y - d.y);
+    a = f2(s0.x + s2.x, s0.y + s2.y);
+    c = f2(s0.x - s2.x, s0.y - s2.y);
+    b = f2(s1.x + s3.y, s1.y - s3.x);
+    d = f2(s1.x - s3.y, s1.y + s3.x);
+}
+
+// forward 16-point DFT, natural-order input v[n]; OUTPUT X[k] is left at v[4*(k&3) + (k>>2)]
+#define FFT16_AT(k) (4 * ((k) & 3) + ((k) >> 2))
+__device__ __forceinline__ void fft16(float2 (&v)[16])
+{
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+    // y[n0][k0] sits at v[n0 + 4*k0]; twiddle by W16^(n0*k0)
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+    v[1 + 4 * 1] = cmul(v[1 + 4 * 1], f2(c1, -s1));      // W^1
+    v[2 + 4 * 1] = cmul(v[2 + 4 * 1], f2(r2, -r2));      // W^2
+    v[3 + 4 * 1] = cmul(v[3 + 4 * 1], f2(s1, -c1));      // W^3
+    v[1 + 4 * 2] = cmul(v[1 + 4 * 2], f2(r2, -r2));      // W^2
+    v[2 + 4 * 2] = f2(v[2 + 4 * 2].y, -v[2 + 4 * 2].x);  // W^4 = -i
+    v[3 + 4 * 2] = cmul(v[3 + 4 * 2], f2(-r2, -r2));    // W^6
+    v[1 + 4 * 3] = cmul(v[1 + 4 * 3], f2(s1, -c1));      // W^3
+    v[2 + 4 * 3] = cmul(v[2 + 4 * 3], f2(-r2, -r2));     // W^6
+    v[3 + 4 * 3] = cmul(v[3 + 4 * 3], f2(-c1, s1));      // W^9
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) dft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
+}
+
+// 4096-point forward FFT.  In: v[n2] = x[tid + 256*n2].  Out: v[FFT16_AT(k2)] = X[tid + 256*k2].
+// s: FFT_SMEM_F2 float2 of LDS scratch, tw: 4096-entry table exp(-2 pi i j / 4096) in LDS.
+// The caller must __syncthreads() before reusing s after return.
+__device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2* tw, int tid)
+{
+    fft16(v);                                            // over n2 -> k0
+#pragma unroll
+    for (int k0 = 1; k0 < 16; ++k0) v[FFT16_AT(k0)] = cmul(v[FFT16_AT(k0)], tw[(tid * k0) & 4095]);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) s[k0 * FFT_EX1_LD + tid] = v[FFT16_AT(k0)];
+    __syncthreads();
+    const int lo = tid & 15, hi = tid >> 4;              // (n0, k0)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = s[hi * FFT_EX1_LD + n1 * 16 + lo];
+    fft16(v);                                            // over n1 -> k1
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[FFT16_AT(k1)] = cmul(v[FFT16_AT(k1)], tw[(16 * lo * k1) & 4095]);
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) s[lo * FFT_EX2_LD + k1 * 16 + hi] = v[FFT16_AT(k1)];
+    __syncthreads();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = s[n0 * FFT_EX2_LD + tid];   // tid = k0 + 16*k1
+    fft16(v);                                            // over n0 -> k2
+}
+
+#define STFT_FPB 4      // frames per workgroup (amortises the twiddle-table load; consecutive frames share 75% of input)
+
+__global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
+{
+    __shared__ float2 s_tw[4096];
+    __shared__ float2 s_x[FFT_SMEM_F2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) s_tw[i] = p.tab.twiddle[i];
+    __syncthreads();
+
+    for (int fi = 0; fi < STFT_FPB; ++fi) {
+        const int f = blockIdx.x * STFT_FPB + fi;
+        if (f >= p.rows_total) break;
+        const int tile = f / p.T, t = f % p.T;
+        float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
+        float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
+        float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
+        float2* specR = specL + p.spec_ch_stride;
+        if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
+            for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
+            if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
+            continue;
+        }
+        const size_t pos = (size_t)f * SRT_HOP;
+        float2 v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int n = tid + 256 * n2;
+            const float w = p.tab.preWin[n];
+            const bool ok = pos + n < p.nsamples;        // tail frame is zero padded (stftFix.c:460-472)
+            v[n2] = f2(ok ? p.L[pos + n] * w : 0.f, ok ? p.R[pos + n] * w : 0.f);
+        }
+        fft4096(v, s_x, s_tw, tid);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) s_x[tid + 256 * k2] = v[FFT16_AT(k2)];
+        __syncthreads();
+        // separate the two real spectra; stored spectrum = conj(F) (the reference's re/im convention)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = tid + 256 * j;
+            if (k <= 2048) {
+                const float2 zk = s_x[k], zm = s_x[(4096 - k) & 4095];
+                const float2 sl = f2(zk.x + zm.x, zm.y - zk.y);
+                const float2 sr = f2(zk.y + zm.y, zk.x - zm.x);
+                specL[k] = sl;
+                specR[k] = sr;
+                if (p.mag && k < p.F) {
+                    magL[k] = hypotf(sl.x, sl.y) * 4096.0f;          // main.c:468-469
+                    magR[k] = hypotf(sr.x, sr.y) * 4096.0f;
+                }
+            } else if (k < SRT_SPEC_LD) {
+                specL[k] = f2(0.f, 0.f);
+                specR[k] = f2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
+{
+    const int blocks = (p.rows_total + STFT_FPB - 1) / STFT_FPB;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+#define ISTFT_FPB 2
+
+// per frame: read the spectrum row once, then for every stem: mask multiply -> inverse FFT -> post-window -> frame buffer
+__global__ void __launch_bounds__(256) srt_istft_kernel(const SrtIstftParams p)
+{
+    __shared__ float2 s_tw[4096];
+    __shared__ float2 s_x[FFT_SMEM_F2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) s_tw[i] = p.tab.twiddle[i];
+    __syncthreads();
+    const size_t tf = (size_t)p.T * p.F;
+
+    for (int fi = 0; fi < ISTFT_FPB; ++fi) {
+        const int f = blockIdx.x * ISTFT_FPB + fi;
+        if (f >= p.frames) break;
+        const int tile = f / p.T, t = f % p.T;
+        const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
+        const float2* specR = specL + p.spec_ch_stride;
+        float2 sl[9], sr[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = tid + 256 * j;
+            if (k <= 2048) { sl[j] = specL[k]; sr[j] = specR[k]; }
+        }
+        for (int st = 0; st < p.nstems; ++st) {
+            const float* mL = p.masks ? p.masks + ((size_t)(st * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
+            const float* mR = mL ? mL + tf : nullptr;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = tid + 256 * j;
+                if (k <= 2048) {
+                    float gl = p.oob[st], gr = p.oob[st];                   // bins >= F: "unaffectedWeight" (main.c:486-493)
+                    if (k < p.F) { gl = mL ? mL[k] : 1.0f; gr = mR ? mR[k] : 1.0f; }
+                    const float reL = sl[j].x * gl, imL = sl[j].y * gl, reR = sr[j].x * gr, imR = sr[j].y * gr;
+                    // G = F'_L + i F'_R with F' = re - i im, Hermitian-extended; stored swapped (im,re) for the inverse-by-forward trick
+                    if (k == 0) s_x[0] = f2(reR, reL);                     // a[0] = re[0]            (stftFix.c:556-557)
+                    else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);   // rev[2048]: re - im wins (stftFix.c:563-566)
+                    else {
+                        s_x[k] = f2(reR - imL, reL + imR);
+                        s_x[4096 - k] = f2(reR + imL, reL - imR);
+                    }
+                }
+            }
+            __syncthreads();
+            float2 v[16];
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
+            __syncthreads();
+            fft4096(v, s_x, s_tw, tid);
+            float* oL = p.frames_out + ((size_t)(st * 2 + 0) * p.frames + f) * SRT_FFT;
+            float* oR = p.frames_out + ((size_t)(st * 2 + 1) * p.frames + f) * SRT_FFT;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const int q = tid + 256 * k2;
+                const float w = p.tab.postWin[q];
+                const float2 y = v[FFT16_AT(k2)];                          // swapped back: L = y.y, R = y.x
+                oL[q] = y.y * w;
+                oR[q] = y.x * w;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[i] = sum of the (up to) four frames covering sample i, added in frame order (stftFix.c:570-575)
+__global__ void srt_ola_kernel(const SrtIstftParams p)
+{
+    const size_t total = (size_t)p.nstems * 2 * p.out_len;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e % p.out_len, sc = e / p.out_len;            // sc = stem*2 + ch
+        const int seg = (int)(i / SRT_HOP), q = (int)(i % SRT_HOP);
+        const float* fr = p.frames_out + sc * (size_t)p.frames * SRT_FFT;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = seg - 3 + j;
+            if (f >= 0 && f < p.frames) acc += fr[(size_t)f * SRT_FFT + q + (3 - j) * SRT_HOP];
+        }
+        p.out[sc * p.out_len + i] = acc;
+    }
+}
+
+int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
+{
+    if (p.frames <= 0) return 0;
+    hipLaunchKernelGGL(srt_istft_kernel, dim3((p.frames + ISTFT_FPB - 1) / ISTFT_FPB), dim3(256), 0, s, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+    const size_t total = (size_t)p.nstems * 2 * p.out_len;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(srt_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

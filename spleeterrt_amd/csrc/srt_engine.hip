@@ -1,0 +1,370 @@
+// srt_engine.hip — engine object, HBM layout and the device-resident C ABI (include/spleeterrt_amd.h).
+//
+// HBM layout (all fp32, instance = (stem, tile), CHW planar, row = time, contiguous = frequency):
+//   coeff[stem]           raw spleeterCoeff blob (Executable/spleeter.h:5-31), biases / BN read in place
+//   wpack[stem][layer]    GEMM-ready weights [Cin][25][CP]
+//   raw[i]  i=0..5        encoder conv+bias outputs (the skip tensors)   [stem][tile][Cout][H>>i+1][W>>i+1]
+//   act[i]  i=0..4        BN+activation copies feeding the next encoder layer
+//   up[i]   i=0..5        decoder outputs (new channels only; the concat is done by pointer)
+//   spec / mag / masks / frames / pcm for the DSP stages
+#include "srt_internal.h"
+#include "../../include/spleeterrt_amd.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* detail = "")
+{
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(-2, "HIP error: %s", hipGetErrorString(_e)); } while (0)
+
+static const int ENC_CH[6][2] = { {2, 16}, {16, 32}, {32, 64}, {64, 128}, {128, 256}, {256, 512} };
+static const int DEC_CH[6][2] = { {512, 256}, {512, 128}, {256, 64}, {128, 32}, {64, 16}, {32, 1} };
+
+struct LayerOff { size_t w, b, bn; int cin, cout, cp; };
+struct Layout { LayerOff down[6], up[6]; size_t head_w, head_b, total; };
+
+static Layout make_layout()
+{
+    Layout lo; size_t o = 0;
+    for (int i = 0; i < 6; ++i) {
+        LayerOff& L = lo.down[i]; L.cin = ENC_CH[i][0]; L.cout = ENC_CH[i][1]; L.cp = (L.cout + 31) / 32 * 32;
+        L.w = o; o += (size_t)25 * L.cin * L.cout; L.b = o; o += L.cout; L.bn = o; if (i < 5) o += 2 * (size_t)L.cout;
+    }
+    for (int i = 0; i < 6; ++i) {
+        LayerOff& L = lo.up[i]; L.cin = DEC_CH[i][0]; L.cout = DEC_CH[i][1]; L.cp = (L.cout + 31) / 32 * 32;
+        L.w = o; o += (size_t)25 * L.cin * L.cout; L.b = o; o += L.cout; L.bn = o; o += 2 * (size_t)L.cout;
+    }
+    lo.head_w = o; o += 32; lo.head_b = o; o += 2; lo.total = o;
+    return lo;
+}
+
+struct TimingEntry { std::string name; hipEvent_t a, b; };
+
+struct srt_engine {
+    srt_config cfg;
+    hipStream_t stream;
+    Layout lo;
+    float* coeff_all;                                  // [n_stems][SRT_COEFF_STRIDE]
+    float* wpack_down[6]; float* wpack_up[6];          // per layer: [n_stems][Cin*25*CP]
+    size_t wpack_down_stem[6], wpack_up_stem[6];
+    bool   have_coeff[SRT_MAX_STEMS];
+    float* raw[6]; float* act[5]; float* up[6];
+    size_t raw_tile[6], act_tile[5], up_tile[6];       // floats per instance
+    // DSP
+    float *preWin, *postWin; float2* twiddle;
+    float2* spec; float* mag; float* masks; float* frames;
+    size_t rows_cap;
+    int last_ntiles;
+    // timing
+    bool timing; std::vector<TimingEntry> tlog;
+};
+
+const char* srtLastError(void) { return g_err; }
+size_t srtCoeffBytes(void) { return (size_t)SRT_COEFF_FLOATS * 4; }
+size_t srtStftRows(size_t n) { return (n + SRT_HOP - 1) / SRT_HOP; }
+size_t srtStftFrames(size_t n) { return n < SRT_FFT ? 0 : (n - SRT_FFT + SRT_HOP / 4) / SRT_HOP + 1; }   // stftFix.c:378 + tail frame
+size_t srtIstftLength(size_t rows) { return rows * SRT_HOP + (SRT_FFT - SRT_HOP); }
+
+struct TimerScope {
+    srt_engine* e; size_t idx; bool on;
+    TimerScope(srt_engine* e_, const char* name) : e(e_), idx(0), on(e_->timing) {
+        if (!on) return;
+        TimingEntry t; t.name = name;
+        hipEventCreate(&t.a); hipEventCreate(&t.b);
+        hipEventRecord(t.a, e->stream);
+        e->tlog.push_back(t); idx = e->tlog.size() - 1;
+    }
+    ~TimerScope() { if (on) hipEventRecord(e->tlog[idx].b, e->stream); }
+};
+
+static void free_all(srt_engine* e)
+{
+    if (e->coeff_all) hipFree(e->coeff_all);
+    for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
+    for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act[i]) hipFree(e->act[i]); }
+    void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->mag, e->masks, e->frames };
+    for (void* m : misc) if (m) hipFree(m);
+    for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+}
+
+int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
+{
+    if (!cfg || !out) return fail(-1, "srtCreate: null argument");
+    if (cfg->F < 64 || cfg->F > 2048 || cfg->F % 64 || cfg->T < 64 || cfg->T % 64)
+        return fail(-1, "srtCreate: F and T must be multiples of 64 (F <= 2048)");     // spleeter.c:113-119 floor-divides by 64
+    if (cfg->n_stems < 1 || cfg->n_stems > SRT_MAX_STEMS || cfg->max_tiles < 1) return fail(-1, "srtCreate: bad n_stems / max_tiles");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "srtCreate: no HIP device (this library has no CPU path)");
+    srt_engine* e = new srt_engine();
+    e->coeff_all = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
+    memset(e->have_coeff, 0, sizeof e->have_coeff);
+    memset(e->raw, 0, sizeof e->raw); memset(e->act, 0, sizeof e->act); memset(e->up, 0, sizeof e->up);
+    e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->mag = e->masks = e->frames = nullptr;
+    e->cfg = *cfg; e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
+    if (e->lo.total != SRT_COEFF_FLOATS) { delete e; return fail(-4, "internal: weight layout size mismatch"); }
+    const size_t S = cfg->n_stems, NT = cfg->max_tiles, HW = (size_t)cfg->T * cfg->F;
+#define EALLOC(ptr, nfloats) do { if (hipMalloc((void**)&(ptr), (nfloats) * sizeof(float)) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); } } while (0)
+    EALLOC(e->coeff_all, S * SRT_COEFF_STRIDE);
+    for (int i = 0; i < 6; ++i) {
+        e->wpack_down_stem[i] = (size_t)e->lo.down[i].cin * 25 * e->lo.down[i].cp;
+        e->wpack_up_stem[i] = (size_t)e->lo.up[i].cin * 25 * e->lo.up[i].cp;
+        EALLOC(e->wpack_down[i], S * e->wpack_down_stem[i]);
+        EALLOC(e->wpack_up[i], S * e->wpack_up_stem[i]);
+    }
+    for (int i = 0; i < 6; ++i) {
+        e->raw_tile[i] = (size_t)ENC_CH[i][1] * (HW >> (2 * (i + 1)));
+        EALLOC(e->raw[i], S * NT * e->raw_tile[i]);
+        if (i < 5) { e->act_tile[i] = e->raw_tile[i]; EALLOC(e->act[i], S * NT * e->act_tile[i]); }
+        e->up_tile[i] = (size_t)DEC_CH[i][1] * (HW >> (2 * (5 - i)));
+        EALLOC(e->up[i], S * NT * e->up_tile[i]);
+    }
+    e->rows_cap = NT * cfg->T;
+    EALLOC(e->preWin, SRT_FFT); EALLOC(e->postWin, SRT_FFT); EALLOC(e->twiddle, 2 * SRT_FFT);
+    EALLOC(e->spec, 2 * 2 * e->rows_cap * SRT_SPEC_LD);
+    EALLOC(e->mag, NT * 2 * HW);
+    EALLOC(e->masks, S * NT * 2 * HW);
+    EALLOC(e->frames, S * 2 * e->rows_cap * SRT_FFT);
+#undef EALLOC
+    // tables: same formulas and float rounding as InitSTFT (stftFix.c:302-313)
+    std::vector<float> pre(SRT_FFT), post(SRT_FFT), tw(2 * SRT_FFT), sig(1026);
+    const double w0 = 6.283185307179586476925286766559 / SRT_FFT;
+    const float postScale = (float)SRT_FFT * ((1.0f / 2.0f) / (3.0f / 8.0f));
+    for (int i = 0; i < SRT_FFT; ++i) {
+        const float hs = (float)((1.0 / SRT_FFT) * (0.5 * (1.0 - cos(w0 * (i + 0.5)))));
+        pre[i] = hs * (2.0f / 4.0f);
+        post[i] = hs * postScale * 0.5f;
+        tw[2 * i] = (float)cos(w0 * i); tw[2 * i + 1] = (float)(-sin(w0 * i));
+    }
+    // logistic LUT of the Executable flavour (spleeter.c:29): 1025 samples on [-7,7] + trailing 1.0, regenerated in closed form
+    for (int i = 0; i < 1025; ++i) sig[i] = (float)(1.0 / (1.0 + exp(7.0 - 0.013671875 * i)));
+    sig[1025] = 1.0f;
+    if (hipMemcpy(e->preWin, pre.data(), SRT_FFT * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->postWin, post.data(), SRT_FFT * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->twiddle, tw.data(), 2 * SRT_FFT * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        srt_set_sigmoid_table(sig.data()) != 0) { free_all(e); delete e; return fail(-2, "srtCreate: table upload failed"); }
+    *out = e;
+    return 0;
+}
+
+void srtDestroy(srt_engine* e)
+{
+    if (!e) return;
+    hipStreamSynchronize(e->stream);
+    free_all(e);
+    delete e;
+}
+
+static int pack_stem(srt_engine* e, int stem)
+{
+    for (int i = 0; i < 6; ++i) {
+        const LayerOff& D = e->lo.down[i]; const LayerOff& U = e->lo.up[i];
+        const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
+        if (srt_launch_pack_enc(c + D.w, e->wpack_down[i] + stem * e->wpack_down_stem[i], D.cin, D.cout, D.cp, e->stream)) return fail(-2, "pack launch failed");
+        if (srt_launch_pack_dec(c + U.w, e->wpack_up[i] + stem * e->wpack_up_stem[i], U.cin, U.cout, U.cp, e->stream)) return fail(-2, "pack launch failed");
+    }
+    e->have_coeff[stem] = true;
+    return 0;
+}
+
+int srtSetCoeffHost(srt_engine* e, int stem, const void* h)
+{
+    if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffHost: bad argument");
+    HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, h, srtCoeffBytes(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return pack_stem(e, stem);
+}
+int srtSetCoeffDevice(srt_engine* e, int stem, const void* d)
+{
+    if (!e || !d || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffDevice: bad argument");
+    HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, d, srtCoeffBytes(), hipMemcpyDeviceToDevice, e->stream));
+    return pack_stem(e, stem);
+}
+int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
+{
+    if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffFp16Host: bad argument");
+    uint16_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)SRT_COEFF_FLOATS * 2));
+    hipError_t er = hipMemcpyAsync(d, h, (size_t)SRT_COEFF_FLOATS * 2, hipMemcpyHostToDevice, e->stream);
+    if (er == hipSuccess) { srt_fp16_expand(d, e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, SRT_COEFF_FLOATS, e->stream); er = hipStreamSynchronize(e->stream); }
+    hipFree(d);
+    HIPCHK(er);
+    return pack_stem(e, stem);
+}
+
+
+int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
+{
+    if (!e || !d_mag || !d_masks) return fail(-1, "srtForward: null argument");
+    if (ntiles < 1 || ntiles > e->cfg.max_tiles) return fail(-1, "srtForward: ntiles exceeds max_tiles");
+    const int S = e->cfg.n_stems, T = e->cfg.T, F = e->cfg.F;
+    for (int s = 0; s < S; ++s) if (!e->have_coeff[s]) return fail(-5, "srtForward: weights not set for every stem");
+    // the activation pair is per engine (spleeter.c:130-139 is per instance); the kernels take one kind per launch,
+    // so stems with different modes are launched as separate groups.
+    const size_t HW = (size_t)T * F;
+    e->last_ntiles = ntiles;
+    for (int s0 = 0; s0 < S;) {
+        int s1 = s0 + 1;
+        while (s1 < S && (e->cfg.stem_mode[s1] != 0) == (e->cfg.stem_mode[s0] != 0)) ++s1;
+        const int ns = s1 - s0;
+        const int actE = e->cfg.stem_mode[s0] ? SRT_ACT_ELU : SRT_ACT_LEAKY, actD = e->cfg.stem_mode[s0] ? SRT_ACT_ELU : SRT_ACT_RELU;
+        const float* cbase = e->coeff_all + (size_t)s0 * SRT_COEFF_STRIDE;
+        char nm[32];
+        for (int i = 0; i < 6; ++i) {                                           // encoder (spleeter.c:182-238)
+            const LayerOff& L = e->lo.down[i];
+            SrtConvParams p; memset(&p, 0, sizeof p);
+            p.Cin = L.cin; p.Cout = L.cout; p.H = T >> i; p.W = F >> i; p.CA = L.cin; p.ntiles = ntiles; p.nstems = ns;
+            if (i == 0) { p.srcA = d_mag; p.srcA_stem = 0; p.srcA_tile = 2 * HW; }                 // every stem reads the same magnitudes
+            else { p.srcA = e->act[i - 1] + (size_t)s0 * ntiles * e->act_tile[i - 1]; p.srcA_stem = (size_t)ntiles * e->act_tile[i - 1]; p.srcA_tile = e->act_tile[i - 1]; }
+            p.srcB = p.srcA;
+            p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = i < 5 ? cbase + L.bn : nullptr; p.bnScale = i < 5 ? cbase + L.bn + L.cout : nullptr;
+            p.coeff_stem = SRT_COEFF_STRIDE;
+            p.wpack = e->wpack_down[i] + (size_t)s0 * e->wpack_down_stem[i]; p.wpack_stem = e->wpack_down_stem[i];
+            p.CP = L.cp;
+            p.outRaw = e->raw[i] + (size_t)s0 * ntiles * e->raw_tile[i];
+            p.outAct = i < 5 ? e->act[i] + (size_t)s0 * ntiles * e->act_tile[i] : nullptr;
+            p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
+            p.act = actE; p.variant = e->cfg.variant;
+            snprintf(nm, sizeof nm, "down%d", i + 1);
+            TimerScope ts(e, nm);
+            if (srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
+        }
+        for (int i = 0; i < 6; ++i) {                                           // decoder (spleeter.c:239-294)
+            const LayerOff& L = e->lo.up[i];
+            SrtConvParams p; memset(&p, 0, sizeof p);
+            p.Cin = L.cin; p.Cout = L.cout; p.H = T >> (6 - i); p.W = F >> (6 - i); p.ntiles = ntiles; p.nstems = ns;
+            const int sk = 5 - i;                                               // skip tensor = raw[5-i]; up1 consumes conv6 alone
+            p.srcA = e->raw[sk] + (size_t)s0 * ntiles * e->raw_tile[sk]; p.srcA_stem = (size_t)ntiles * e->raw_tile[sk]; p.srcA_tile = e->raw_tile[sk];
+            if (i == 0) { p.CA = L.cin; p.srcB = p.srcA; }
+            else {
+                p.CA = L.cin / 2;
+                p.srcB = e->up[i - 1] + (size_t)s0 * ntiles * e->up_tile[i - 1]; p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];
+            }
+            p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
+            p.coeff_stem = SRT_COEFF_STRIDE;
+            p.wpack = e->wpack_up[i] + (size_t)s0 * e->wpack_up_stem[i]; p.wpack_stem = e->wpack_up_stem[i];
+            p.CP = L.cp;
+            p.outRaw = nullptr;
+            p.outAct = e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
+            p.out_stem = (size_t)ntiles * e->up_tile[i]; p.out_tile = e->up_tile[i];
+            p.act = actD; p.variant = e->cfg.variant;
+            snprintf(nm, sizeof nm, "up%d", i + 1);
+            TimerScope ts(e, nm);
+            if (srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
+        }
+        {                                                                       // head (spleeter.c:295-300)
+            SrtHeadParams h; memset(&h, 0, sizeof h);
+            h.H = T; h.W = F; h.ntiles = ntiles; h.nstems = ns;
+            h.src = e->up[5] + (size_t)s0 * ntiles * e->up_tile[5]; h.src_stem = (size_t)ntiles * e->up_tile[5]; h.src_tile = e->up_tile[5];
+            h.w = cbase + e->lo.head_w; h.bias = cbase + e->lo.head_b; h.coeff_stem = SRT_COEFF_STRIDE;
+            h.out = d_masks + (size_t)s0 * ntiles * 2 * HW; h.out_stem = (size_t)ntiles * 2 * HW; h.out_tile = 2 * HW;
+            h.variant = e->cfg.variant;
+            TimerScope ts(e, "up7");
+            if (srt_launch_head(h, e->stream)) return fail(-2, "head launch failed");
+        }
+        s0 = s1;
+    }
+    return 0;
+}
+
+static SrtDspTables tables_of(const srt_engine* e) { SrtDspTables t; t.preWin = e->preWin; t.postWin = e->postWin; t.twiddle = e->twiddle; return t; }
+
+int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_spec, float* d_mag)
+{
+    if (!e || !d_L || !d_R || !d_spec) return fail(-1, "srtStft: null argument");
+    if (n < SRT_FFT) return fail(-1, "srtStft: need at least 4096 samples");          // the reference underflows here (stftFix.c:378)
+    const size_t rows = srtStftRows(n);
+    const int T = e->cfg.T;
+    const size_t ntiles = (rows + T - 1) / T;
+    if (d_mag && ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtStft: signal longer than max_tiles * T frames");
+    SrtStftParams p; memset(&p, 0, sizeof p);
+    p.L = d_L; p.R = d_R; p.nsamples = n;
+    p.frames_computed = (int)srtStftFrames(n);
+    p.rows_total = (int)rows;
+    p.spec = (float2*)d_spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
+    p.mag = nullptr; p.T = T; p.F = e->cfg.F; p.tab = tables_of(e);
+    if (d_mag) {
+        // magnitude rows exist for whole tiles: rows..ntiles*T are zero (main.c:507-514)
+        p.mag = d_mag;
+        if (ntiles * T > rows) HIPCHK(hipMemsetAsync(d_mag, 0, ntiles * 2 * (size_t)T * e->cfg.F * sizeof(float), e->stream));
+    }
+    TimerScope ts(e, "stft");
+    if (srt_launch_stft(p, e->stream)) return fail(-2, "stft launch failed");
+    return 0;
+}
+
+int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out)
+{
+    if (!e || !d_spec || !d_out) return fail(-1, "srtIstft: null argument");
+    if (rows < 1 || rows > e->rows_cap) return fail(-1, "srtIstft: rows exceed max_tiles * T");
+    const int T = e->cfg.T;
+    SrtIstftParams p; memset(&p, 0, sizeof p);
+    p.spec = (const float2*)d_spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
+    p.frames = (int)rows; p.masks = d_masks; p.nstems = e->cfg.n_stems; p.ntiles = (int)((rows + T - 1) / T);
+    p.T = T; p.F = e->cfg.F;
+    for (int s = 0; s < SRT_MAX_STEMS; ++s) p.oob[s] = e->cfg.oob_weight[s];
+    p.frames_out = e->frames; p.out = d_out; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
+    TimerScope ts(e, "istft");
+    if (srt_launch_istft(p, e->stream)) return fail(-2, "istft launch failed");
+    return 0;
+}
+
+int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_out)
+{
+    if (!e) return fail(-1, "srtSeparate: null engine");
+    const size_t rows = srtStftRows(n);
+    const int T = e->cfg.T;
+    const size_t ntiles = (rows + T - 1) / T;
+    if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparate: signal longer than max_tiles * T frames");
+    int rc = srtStft(e, d_L, d_R, n, (float*)e->spec, e->mag);
+    if (rc) return rc;
+    rc = srtForward(e, e->mag, (int)ntiles, e->masks);
+    if (rc) return rc;
+    return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+}
+
+int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_dst, size_t max_floats)
+{
+    if (!e || !name || !h_dst) return fail(-1, "srtCopyTensor: null argument");
+    const int idx = name[strlen(name) - 1] - '1';
+    const float* base = nullptr; size_t per = 0;
+    if (!strncmp(name, "conv", 4) && idx >= 0 && idx < 6) { base = e->raw[idx]; per = e->raw_tile[idx]; }
+    else if (!strncmp(name, "act", 3) && idx >= 0 && idx < 5) { base = e->act[idx]; per = e->act_tile[idx]; }
+    else if (!strncmp(name, "up", 2) && idx >= 0 && idx < 6) { base = e->up[idx]; per = e->up_tile[idx]; }
+    else return fail(-1, "srtCopyTensor: unknown tensor %s", name);
+    if (per > max_floats) return fail(-1, "srtCopyTensor: destination too small");
+    // instance stride = ntiles of the last srtForward call
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h_dst, base + ((size_t)stem * e->last_ntiles + tile) * per, per * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)0;
+}
+
+int srtSetTiming(srt_engine* e, int enable)
+{
+    if (!e) return fail(-1, "null engine");
+    for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    e->tlog.clear();
+    e->timing = enable != 0;
+    return 0;
+}
+
+int srtGetTiming(srt_engine* e, char* names, size_t names_bytes, float* ms, int max_entries)
+{
+    if (!e) return fail(-1, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int n = 0; size_t used = 0;
+    if (names && names_bytes) names[0] = 0;
+    for (auto& t : e->tlog) {
+        if (n >= max_entries) break;
+        float v = 0; hipEventElapsedTime(&v, t.a, t.b);
+        ms[n++] = v;
+        if (names && used + t.name.size() + 2 < names_bytes) { memcpy(names + used, t.name.c_str(), t.name.size()); used += t.name.size(); names[used++] = ','; names[used] = 0; }
+    }
+    return n;
+}

@@ -1,0 +1,81 @@
+// srt_internal.h — private declarations shared by the HIP translation units of libspleeterrt_amd.so.
+// Nothing here is part of the C ABI (see include/*.h for that).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define SRT_MAX_STEMS 8
+#define SRT_FFT 4096
+#define SRT_HOP 1024
+#define SRT_HALF 2049
+#define SRT_SPEC_LD 2052          // float2 elements per spectrum row (2049 padded to a 16-byte multiple)
+#define SRT_COEFF_FLOATS 9822725u // sizeof(spleeterCoeff)/4, Executable/spleeter.h:5-31
+#define SRT_COEFF_STRIDE 9822784u // per-stem stride inside the engine's single weight allocation (64-float aligned)
+
+enum { SRT_ACT_LEAKY = 0, SRT_ACT_RELU = 1, SRT_ACT_ELU = 2 };
+
+// One convolution layer evaluated for nstems x ntiles independent instances.
+// instance pointer = base + stem * *_stem + tile * *_tile   (strides in floats)
+struct SrtConvParams {
+    int Cin, Cout;        // channels
+    int H, W;             // INPUT spatial size per instance (encoder output = H/2 x W/2, decoder output = 2H x 2W)
+    int CA;               // channels [0,CA) come from srcA, [CA,Cin) from srcB (decoder skip concat by pointer)
+    int ntiles, nstems;
+    const float* srcA; size_t srcA_stem, srcA_tile;
+    const float* srcB; size_t srcB_stem, srcB_tile;
+    // per-stem weights: pointer = base + stem * stride (all stems live in one allocation, so no pointer tables)
+    const float* wraw;    // reference layout: encoder OIHW [Cout][Cin][5][5], decoder [Cin][Cout][5][5]
+    const float* bias; const float* bnShift; const float* bnScale;   // bnScale == nullptr => no batch-norm (down6)
+    size_t coeff_stem;    // stride (floats) between stems for wraw/bias/bnShift/bnScale
+    const float* wpack;   // GEMM layout [Cin][25][CP], zero padded to CP output channels
+    size_t wpack_stem;
+    int CP;
+    float* outRaw;        // encoder: conv+bias (skip tensor); decoder: unused
+    float* outAct;        // encoder: act(bn(v)); decoder: bn(act(v))
+    size_t out_stem, out_tile;
+    int act, variant;
+};
+
+struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sigmoid  (spleeter.c:156,295-300)
+    int H, W, ntiles, nstems;
+    const float* src; size_t src_stem, src_tile;
+    const float* w; const float* bias; size_t coeff_stem;
+    float* out; size_t out_stem, out_tile;    // [2][H][W] per instance
+    int variant;
+};
+
+// launchers (srt_nn.hip)
+int  srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s);
+int  srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s);
+int  srt_launch_head(const SrtHeadParams& p, hipStream_t s);
+int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
+int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
+int  srt_set_sigmoid_table(const float* tbl1026);
+void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);
+
+// DSP launchers (srt_dsp.hip)
+struct SrtDspTables { const float* preWin; const float* postWin; const float2* twiddle; };
+struct SrtStftParams {
+    const float* L; const float* R; size_t nsamples;
+    int frames_computed;      // frames that get an FFT (tail frame zero padded); rows beyond are zero
+    int rows_total;           // rows to write (>= frames_computed): spectrum + magnitude rows (zero filled)
+    float2* spec;             // [2][spec_rows][SRT_SPEC_LD]
+    size_t spec_ch_stride;    // float2 elements between channels
+    float* mag;               // [ntiles][2][T][F] or nullptr
+    int T, F;
+    SrtDspTables tab;
+};
+struct SrtIstftParams {
+    const float2* spec; size_t spec_ch_stride;
+    int frames;               // rows to synthesise
+    const float* masks;       // [nstems][ntiles][2][T][F] or nullptr (all-ones)
+    int nstems, ntiles, T, F;
+    float oob[SRT_MAX_STEMS];
+    float* frames_out;        // [nstems][2][frames][4096] windowed time frames (temp)
+    float* out;               // [nstems][2][out_len]
+    size_t out_len;           // frames*1024 + 3072
+    SrtDspTables tab;
+};
+int srt_launch_stft(const SrtStftParams& p, hipStream_t s);
+int srt_launch_istft(const SrtIstftParams& p, hipStream_t s);

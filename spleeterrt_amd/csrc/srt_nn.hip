@@ -1,0 +1,551 @@
+// srt_nn.hip — U-Net mask network kernels for gfx950 (CDNA4).
+//
+// Replaces, for the hot path only, the reference's im2col + SGEMM + col2im stack:
+//   encoder conv   : Executable/spleeter.c:96-100  + im2col_dilated.c:10-33 + gemm.c:6-19   (K3/K4 in SURVEY §2.2)
+//   decoder tconv  : Executable/spleeter.c:73-78   + gemm.c:33-45 + im2col_dilated.c:42-65   (K5/K6)
+//   head + sigmoid : Executable/spleeter.c:295-300, :30-42                                    (K7)
+//
+// Design (not a translation): no im2col/col buffer is ever materialised.
+//   * encoder: implicit GEMM.  A workgroup stages the input patch of KC channels in LDS with the columns
+//     de-interleaved by parity (stride-2 taps then read consecutive LDS words), stages the matching slab of
+//     K-major packed weights, and issues v_mfma_f32_32x32x2_f32 with the k-pair = two input channels of one tap.
+//   * decoder: gather form.  out[2a+py][2b+px] only receives taps with ky = py+1 (mod 2), kx = px+1 (mod 2), so the
+//     transposed conv is 4 parity-class convolutions over the SAME input patch: no scatter, no atomics,
+//     deterministic, epilogue (bias -> act -> BN) fused, the skip concat is two source pointers.
+//   * global->LDS staging is register-prefetched one K-chunk ahead so HBM/L2 latency hides under the MFMAs.
+// The naive kernels are a bit-simple cross-check path (SRT_IMPL_NAIVE) and serve layers not yet on MFMA.
+#include "srt_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------- activations
+__device__ float g_sigmoid_tbl[1026];
+
+int srt_set_sigmoid_table(const float* tbl1026)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sigmoid_tbl), tbl1026, 1026 * sizeof(float)) == hipSuccess ? 0 : -1;
+}
+
+// The epilogue math keeps the reference's operation order with contraction off, so the only difference
+// from the CPU path is the summation order inside the dot products.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float srt_act(float x, int kind, int variant)
+{
+    if (kind == SRT_ACT_LEAKY) return x >= 0.0f ? x : 0.2f * x;          // Executable/spleeter.c:43-46
+    if (kind == SRT_ACT_RELU) return x >= 0.0f ? x : 0.0f;               // :47-50
+    if (variant == 0 && x < -15.0f) return -1.0f;                        // :51-56 (VST flavour has no clamp)
+    return x >= 0.0f ? x : expf(x) - 1.0f;
+}
+__device__ __forceinline__ float srt_sigmoid(float x, int variant)
+{
+    if (variant == 0) {                                                  // LUT, Executable/spleeter.c:30-42
+        if (x > 7.0f) return 1.0f;
+        if (x < -7.0f) return 0.0f;
+        const float step = 0.01367188f;
+        short idx = (short)((x + 7.0f) / step);
+        float x1 = -7.0f + step * idx;
+        float t0 = g_sigmoid_tbl[idx], t1 = g_sigmoid_tbl[idx + 1];
+        return t0 + (t1 - t0) / (-7.0f + step * (idx + 1) - x1) * (x - x1);
+    }
+    if (x >= 0.0f) { float z = expf(-x); return 1.0f / (1.0f + z); }     // VST/Source/spleeter.c:56-65
+    float z = expf(x);
+    return z / (1.0f + z);
+}
+__device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, int act, int variant)
+{
+    return srt_act(scale * v + shift, act, variant);                     // spleeter.c:188: act(bn[C+s]*v + bn[s])
+}
+__device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float scale, float shift, int act, int variant)
+{
+    float v = srt_act(acc + bias, act, variant);                         // spleeter.c:244-245: activation BEFORE BN
+    return scale * v + shift;
+}
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ const float* srt_src_channel(const SrtConvParams& p, int stem, int tile, int ch, size_t hw)
+{
+    return ch < p.CA ? p.srcA + stem * p.srcA_stem + tile * p.srcA_tile + (size_t)ch * hw
+                     : p.srcB + stem * p.srcB_stem + tile * p.srcB_tile + (size_t)(ch - p.CA) * hw;
+}
+
+// ------------------------------------------------------------------------------------------- naive kernels
+__global__ void srt_enc_naive(const SrtConvParams p)
+{
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int stem = blockIdx.y / p.ntiles, tile = blockIdx.y % p.ntiles;
+    const size_t hw = (size_t)p.H * p.W, total = (size_t)p.Cout * Ho * Wo;
+    const float* w = p.wraw + stem * p.coeff_stem;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ox = e % Wo, oy = (e / Wo) % Ho, co = e / ((size_t)Wo * Ho);
+        float acc = 0.0f;
+        for (int ci = 0; ci < p.Cin; ++ci) {
+            const float* x = srt_src_channel(p, stem, tile, ci, hw);
+            const float* wk = w + ((size_t)co * p.Cin + ci) * 25;
+            for (int ky = 0; ky < 5; ++ky) {
+                const int r = 2 * oy + ky - 1;
+                if (r < 0 || r >= p.H) continue;
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int c = 2 * ox + kx - 1;
+                    if (c >= 0 && c < p.W) acc += wk[ky * 5 + kx] * x[(size_t)r * p.W + c];
+                }
+            }
+        }
+        const size_t cs = stem * p.coeff_stem;
+        const float v = acc + p.bias[cs + co];
+        const size_t o = stem * p.out_stem + tile * p.out_tile + e;
+        p.outRaw[o] = v;
+        if (p.bnScale) p.outAct[o] = srt_enc_epilogue(v, p.bnScale[cs + co], p.bnShift[cs + co], p.act, p.variant);
+    }
+}
+
+__global__ void srt_dec_naive(const SrtConvParams p)
+{
+    const int Ho = p.H << 1, Wo = p.W << 1;
+    const int stem = blockIdx.y / p.ntiles, tile = blockIdx.y % p.ntiles;
+    const size_t hw = (size_t)p.H * p.W, total = (size_t)p.Cout * Ho * Wo;
+    const float* w = p.wraw + stem * p.coeff_stem;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int X = e % Wo, Y = (e / Wo) % Ho, co = e / ((size_t)Wo * Ho);
+        float acc = 0.0f;
+        for (int ci = 0; ci < p.Cin; ++ci) {
+            const float* x = srt_src_channel(p, stem, tile, ci, hw);
+            const float* wk = w + ((size_t)ci * p.Cout + co) * 25;
+            for (int ky = (Y + 1) & 1; ky < 5; ky += 2) {
+                const int h = (Y + 1 - ky) >> 1;                      // 2h + ky - 1 == Y
+                if (h < 0 || h >= p.H) continue;
+                for (int kx = (X + 1) & 1; kx < 5; kx += 2) {
+                    const int ww = (X + 1 - kx) >> 1;
+                    if (ww >= 0 && ww < p.W) acc += wk[ky * 5 + kx] * x[(size_t)h * p.W + ww];
+                }
+            }
+        }
+        p.outAct[stem * p.out_stem + tile * p.out_tile + e] =
+            srt_dec_epilogue(acc, p.bias[stem * p.coeff_stem + co], p.bnScale[stem * p.coeff_stem + co], p.bnShift[stem * p.coeff_stem + co], p.act, p.variant);
+    }
+}
+
+// up7 head: direct 16-tap stencil, both output channels per thread (bandwidth kernel; 1 MiB in, 2 MiB out per instance)
+__global__ void srt_head_kernel(const SrtHeadParams p)
+{
+    const int stem = blockIdx.y / p.ntiles, tile = blockIdx.y % p.ntiles;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* x = p.src + stem * p.src_stem + tile * p.src_tile;
+    float* y = p.out + stem * p.out_stem + tile * p.out_tile;
+    float wk[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wk[i] = p.w[stem * p.coeff_stem + i];
+    const float b0 = p.bias[stem * p.coeff_stem], b1 = p.bias[stem * p.coeff_stem + 1];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < hw; e += (size_t)gridDim.x * blockDim.x) {
+        const int w = e % p.W, h = e / p.W;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int r = h + 2 * ky - 3;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int c = w + 2 * kx - 3;
+                const float v = (r >= 0 && r < p.H && c >= 0 && c < p.W) ? x[(size_t)r * p.W + c] : 0.0f;
+                a0 += wk[ky * 4 + kx] * v;
+                a1 += wk[16 + ky * 4 + kx] * v;
+            }
+        }
+        y[e] = srt_sigmoid(a0 + b0, p.variant);
+        y[hw + e] = srt_sigmoid(a1 + b1, p.variant);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- weight packing
+// encoder OIHW [Cout][Cin][25] -> [Cin][25][CP];  decoder [Cin][Cout][25] -> [Cin][25][CP]
+__global__ void srt_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int CP, int dec)
+{
+    const size_t total = (size_t)Cin * 25 * CP;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int co = e % CP, tap = (e / CP) % 25, ci = e / ((size_t)CP * 25);
+        float v = 0.0f;
+        if (co < Cout) v = dec ? w[((size_t)ci * Cout + co) * 25 + tap] : w[((size_t)co * Cin + ci) * 25 + tap];
+        wp[e] = v;
+    }
+}
+int srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 1);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// fp16 container -> fp32, half-denormals flushed to zero, no Inf/NaN special case (main.c:423-434)
+__global__ void srt_fp16_expand_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t h = in[i];
+        uint32_t mag = ((h & 0x7fffu) << 13) + 0x38000000u;
+        if ((h & 0x7c00u) == 0) mag = 0;
+        out[i] = __uint_as_float(mag | ((h & 0x8000u) << 16));
+    }
+}
+void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_fp16_expand_kernel, dim3(2048), dim3(256), 0, s, d_in, d_out, n);
+}
+
+// ------------------------------------------------------------------------------------------- MFMA encoder
+// Workgroup = 256 threads = 4 waves arranged WM x WN.  Output tile = BM channels x (NI instances x TH x TW pixels),
+// split into 32-pixel sub-tiles of SH x SW (SH*SW == 32) so that one v_mfma_f32_32x32x2_f32 covers
+// 32 output channels x one sub-tile.  k-pair of an MFMA = input channels (2cp, 2cp+1) at one tap.
+template <int TW, int SW> struct EncPad {
+    // half-plane width: >= TW+2, chosen so that the SH rows of a sub-tile land on disjoint LDS banks
+    static constexpr int base = TW + 2;
+    static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
+};
+
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
+__global__ void __launch_bounds__(256) srt_enc_mfma(const SrtConvParams p)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
+    static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
+    constexpr int PH = 2 * TH + 3, PCOLS = 2 * TW + 3;
+    constexpr int PWH = EncPad<TW, SW>::value;
+    static_assert(PWH >= TW + 2, "pad");
+    constexpr int ROWS = 2 * PWH, INS = PH * ROWS, CHS = NI * INS;
+    constexpr int NIN = KC * NI * PH * PCOLS, NLD = (NIN + 255) / 256;
+    constexpr int NW4 = KC * 25 * BM / 4, NWL = (NW4 + 255) / 256;
+
+    __shared__ float s_in[KC * CHS];
+    __shared__ __attribute__((aligned(16))) float s_w[KC * 25 * BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave % WM, wn = wave / WM;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int tilesX = (Wo + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
+    const int m0 = blockIdx.y * BM;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* wp = p.wpack + stem * p.wpack_stem;
+
+    float pin[NLD];
+    float4 pw[NWL];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            float v = 0.0f;
+            if (e < NIN) {
+                const int col = e % PCOLS, r = (e / PCOLS) % PH, il = (e / (PCOLS * PH)) % NI, c = e / (PCOLS * PH * NI);
+                const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 + col - 1, tile = tile0 + il;
+                if (tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = srt_src_channel(p, stem, tile, c0 + c, hw)[(size_t)gy * p.W + gx];
+            }
+            pin[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int e = tid + i * 256;
+            if (e < NW4) {
+                const int m4 = e % (BM / 4), row = e / (BM / 4);
+                pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NIN) {
+                const int col = e % PCOLS, r = (e / PCOLS) % PH, il = (e / (PCOLS * PH)) % NI, c = e / (PCOLS * PH * NI);
+                s_in[c * CHS + il * INS + r * ROWS + (col & 1) * PWH + (col >> 1)] = pin[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int e = tid + i * 256;
+            if (e < NW4) *reinterpret_cast<float4*>(&s_w[e * 4]) = pw[i];
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int oy = sy * SH + l31 / SW, ox = sx * SW + l31 % SW;
+        boff[nr] = half * CHS + il * INS + 2 * oy * ROWS + ox;
+    }
+    const int aoff = half * 25 * BM + wm * MR * 32 + l31;
+
+    const int nchunks = p.Cin / KC;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * KC);
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                const int ky = tap / 5, kx = tap % 5;
+                float a[MR], b[NR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[mr] = s_w[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) b[nr] = s_in[boff[nr] + 2 * cp * CHS + ky * ROWS + (kx & 1) * PWH + (kx >> 1)];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: lane holds pixel l31 of each sub-tile and 16 output channels per accumulator
+    const float* bias = p.bias + stem * p.coeff_stem;
+    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : nullptr;
+    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : nullptr;
+    const size_t ohw = (size_t)Ho * Wo;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+        if (tile >= p.ntiles || oy >= Ho || ox >= Wo) continue;
+        const size_t obase = stem * p.out_stem + tile * p.out_tile + (size_t)oy * Wo + ox;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.Cout) {
+                    const float v = acc[mr][nr][r] + bias[m];
+                    p.outRaw[obase + (size_t)m * ohw] = v;
+                    if (scale) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, scale[m], shift[m], p.act, p.variant);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- MFMA decoder
+// Tile is expressed in INPUT-resolution pixels (a,b); the workgroup produces the 2TH x 2TW output patch as four
+// parity-class accumulators.  tap (ky,kx) -> class (py,px) = ((ky+1)&1, (kx+1)&1), input shift dy = (py+1-ky)/2.
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
+__global__ void __launch_bounds__(256) srt_dec_mfma(const SrtConvParams p)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
+    static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
+    constexpr int PH = TH + 2, PC = TW + 2;
+    constexpr int ROWS = PC + 1, INS = PH * ROWS, CHS = NI * INS;
+    constexpr int NIN = KC * NI * PH * PC, NLD = (NIN + 255) / 256;
+    constexpr int NW4 = KC * 25 * BM / 4, NWL = (NW4 + 255) / 256;
+
+    __shared__ float s_in[KC * CHS];
+    __shared__ __attribute__((aligned(16))) float s_w[KC * 25 * BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave % WM, wn = wave / WM;
+    const int tilesX = (p.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
+    const int m0 = blockIdx.y * BM;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* wp = p.wpack + stem * p.wpack_stem;
+
+    float pin[NLD];
+    float4 pw[NWL];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            float v = 0.0f;
+            if (e < NIN) {
+                const int col = e % PC, r = (e / PC) % PH, il = (e / (PC * PH)) % NI, c = e / (PC * PH * NI);
+                const int gy = ty0 + r - 1, gx = tx0 + col - 1, tile = tile0 + il;
+                if (tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = srt_src_channel(p, stem, tile, c0 + c, hw)[(size_t)gy * p.W + gx];
+            }
+            pin[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int e = tid + i * 256;
+            if (e < NW4) {
+                const int m4 = e % (BM / 4), row = e / (BM / 4);
+                pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NIN) {
+                const int col = e % PC, r = (e / PC) % PH, il = (e / (PC * PH)) % NI, c = e / (PC * PH * NI);
+                s_in[c * CHS + il * INS + r * ROWS + col] = pin[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int e = tid + i * 256;
+            if (e < NW4) *reinterpret_cast<float4*>(&s_w[e * 4]) = pw[i];
+        }
+    };
+
+    f32x16 acc[4][MR][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int a = sy * SH + l31 / SW, b = sx * SW + l31 % SW;
+        boff[nr] = half * CHS + il * INS + a * ROWS + b;
+    }
+    const int aoff = half * 25 * BM + wm * MR * 32 + l31;
+
+    const int nchunks = p.Cin / KC;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * KC);
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+            float b[9][NR];
+#pragma unroll
+            for (int sh = 0; sh < 9; ++sh)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    b[sh][nr] = s_in[boff[nr] + 2 * cp * CHS + (sh / 3) * ROWS + (sh % 3)];   // (1+dy)*ROWS + (1+dx)
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                const int ky = tap / 5, kx = tap % 5;
+                const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;     // exact: numerators are even
+                const int cls = py * 2 + px, sh = (dy + 1) * 3 + (dx + 1);
+                float a[MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[mr] = s_w[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[cls][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[sh][nr], acc[cls][mr][nr], 0, 0, 0);
+            }
+        }
+    }
+
+    const float* bias = p.bias + stem * p.coeff_stem;
+    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : nullptr;
+    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : nullptr;
+    const int Ho = p.H << 1, Wo = p.W << 1;
+    const size_t ohw = (size_t)Ho * Wo;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int a = ty0 + sy * SH + l31 / SW, b = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+        if (tile >= p.ntiles || a >= p.H || b >= p.W) continue;
+        const size_t obase = stem * p.out_stem + tile * p.out_tile + (size_t)(2 * a) * Wo + 2 * b;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.Cout) {
+                    const float bi = bias[m], sc = scale[m], sf = shift[m];
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        float2 v;
+                        v.x = srt_dec_epilogue(acc[py * 2 + 0][mr][nr][r], bi, sc, sf, p.act, p.variant);
+                        v.y = srt_dec_epilogue(acc[py * 2 + 1][mr][nr][r], bi, sc, sf, p.act, p.variant);
+                        *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
+static int launch_enc_cfg(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
+    hipLaunchKernelGGL((srt_enc_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
+static int launch_dec_cfg(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
+    hipLaunchKernelGGL((srt_dec_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+static int launch_naive(void (*k)(const SrtConvParams), const SrtConvParams& p, size_t total, hipStream_t s)
+{
+    size_t bx = (total + 255) / 256;
+    if (bx > 65535) bx = 65535;
+    hipLaunchKernelGGL(k, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    if (impl != 0) return launch_naive(srt_enc_naive, p, (size_t)p.Cout * Ho * Wo, s);
+    const int KC2 = 2;
+    (void)KC2;
+    if (p.Cin == 2) return launch_enc_cfg<32, 1, 32, 2, 4, 1, 2>(p, s);                     // down1: K = 50 in one chunk
+    if (p.Cout <= 32) return launch_enc_cfg<32, 1, 32, 2, 4, 1, 4>(p, s);                    // down2
+    if (Wo >= 64) return launch_enc_cfg<64, 2, 32, 2, 4, 1, 4>(p, s);                        // down3/down4 class
+    if (Wo >= 32) return launch_enc_cfg<64, 2, 32, 1, 8, 1, 4>(p, s);                        // down5 class (one instance = 8x32)
+    return launch_enc_cfg<64, 2, 16, 1, 2, 4, 4>(p, s);                                      // down6 class (4 instances of 4x16)
+}
+
+int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
+{
+    if (impl != 0 || p.Cout < 16) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
+    if (p.Cout <= 32) return launch_dec_cfg<32, 1, 32, 2, 4, 1, 4>(p, s);                    // up4/up5: 4 rows x 64 cols
+    if (p.W >= 32) return launch_dec_cfg<64, 2, 32, 1, 4, 1, 4>(p, s);                       // up2/up3: 4 rows x 32 cols
+    return launch_dec_cfg<64, 2, 16, 1, 2, 2, 4>(p, s);                                      // up1: 2 instances of 4x16
+}
+
+int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
+{
+    size_t total = (size_t)p.H * p.W, bx = (total + 255) / 256;
+    if (bx > 65535) bx = 65535;
+    hipLaunchKernelGGL(srt_head_kernel, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

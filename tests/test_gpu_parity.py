@@ -1,0 +1,160 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp32 path, BASELINE.md §4 / SURVEY §8d): mask max-abs <= 2e-4 with the exact sigmoid
+(<= 1e-3 for the LUT flavour, whose table has a 9e-4 step at |x| = 7), stems rel-RMS <= 1e-4 and
+max-abs <= 1e-4 * peak.  Intermediate tensors are checked relative to their own RMS.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MASK_TOL_EXACT = 2e-4
+MASK_TOL_LUT = 1e-3
+
+
+def _engine(**kw):
+    import spleeterrt_amd as srt
+    return srt.Engine(**kw)
+
+
+def _mag_input(oracle, ntiles, T, F, seed=4242):
+    # magnitude-like, positive, with a few strong peaks (same order of magnitude as |STFT|*4096 of +-0.1 noise)
+    x = np.abs(oracle.lcg(seed, ntiles * 2 * T * F, 6.0)).reshape(ntiles, 2, T, F)
+    x[:, :, ::7, ::13] *= 8.0
+    return np.ascontiguousarray(x, np.float32)
+
+
+def _rel_rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+
+
+@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("T,F", [(64, 512), (128, 1024)])
+def test_forward_layers(oracle, coeffs, impl, T, F):
+    import torch
+    import spleeterrt_amd as srt
+    modes = (0, 1)                       # stem 0: LeakyReLU/ReLU ("2stems" vocal), stem 1: ELU/ELU
+    ntiles = 3 if T == 64 else 1
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=4,
+                  impl=srt.IMPL_NAIVE if impl == "naive" else srt.IMPL_MFMA)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    worst = 0.0
+    for s in range(2):
+        for t in range(ntiles):
+            y, taps = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST, want_taps=True)
+            for name, ref in taps.items():
+                got = eng.tensor(name, s, t)
+                err = _rel_rms(got, ref)
+                assert err < 2e-5, "%s stem %d tile %d impl %s: rel rms %g, max abs %g (ref rms %g)" % (
+                    name, s, t, impl, err, np.abs(got - ref).max(), np.sqrt(np.mean(ref ** 2)))
+            d = np.abs(masks[s, t] - y).max()
+            worst = max(worst, d)
+            assert d <= MASK_TOL_EXACT, "mask stem %d tile %d impl %s: max abs %g" % (s, t, impl, d)
+    eng.close()
+    print("forward %s %dx%d worst mask err %.3g" % (impl, T, F, worst))
+
+
+def test_forward_lut_variant(oracle, coeffs):
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    eng = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_EXE, max_tiles=2)
+    eng.set_coeff(0, coeffs(2))
+    x = _mag_input(oracle, 2, T, F, seed=99)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    for t in range(2):
+        y = oracle.forward(coeffs(2), x[t], 1, oracle.VARIANT_EXE)
+        d = np.abs(masks[0, t] - y)
+        assert d.max() <= MASK_TOL_LUT
+        assert np.mean(d > MASK_TOL_EXACT) < 1e-3        # only points straddling the LUT's +-7 clip may exceed the tight bound
+    eng.close()
+
+
+def test_fp16_container(oracle):
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    h = oracle.synth_coeff_fp16(3)
+    # sprinkle half-denormals: the reference flushes them to zero (main.c:431)
+    h = h.copy(); h[1000:1010] = np.arange(1, 11, dtype=np.uint16); h[2000] = 0x8001
+    c = oracle.fp16_expand(h)
+    e1 = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1)
+    e2 = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1)
+    e1.set_coeff_fp16(0, h)
+    e2.set_coeff(0, c)
+    x = torch.from_numpy(_mag_input(oracle, 1, T, F, seed=5)).cuda()
+    assert torch.equal(e1.forward(x), e2.forward(x))      # identical weights -> bit-identical masks
+    e1.close(); e2.close()
+
+
+def test_stft_matches_oracle(oracle):
+    import torch
+    n = 4096 * 6 + 8192 + 1500                               # ragged tail: last frame is zero padded
+    L, R = oracle.synth_audio(n, 777, True)
+    eng = _engine(F=1024, T=64, stem_modes=(1,), max_tiles=2)
+    spec, mag = eng.stft(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    spec = spec.cpu().numpy(); mag = mag.cpu().numpy()
+    re, im = oracle.stft(L, R)
+    rows = re.shape[1]
+    peak = np.abs(re).max()
+    assert spec.shape[1] == rows
+    assert np.abs(spec[:, :, :2049, 0] - re[:, :, :2049]).max() <= 2e-6 * peak
+    assert np.abs(spec[:, :, :2049, 1] - im[:, :, :2049]).max() <= 2e-6 * peak
+    assert np.all(spec[:, :, 2049:, :] == 0)
+    frames = eng.L.srtStftFrames(n)
+    assert np.all(spec[:, frames:, :, :] == 0)              # rows the reference leaves calloc'ed
+    for t in range(mag.shape[0]):
+        ref = oracle.magnitude_tile(re, im, t * 64, 64, 1024)
+        assert np.abs(mag[t] - ref).max() <= 2e-6 * np.abs(ref).max()
+    eng.close()
+
+
+def test_istft_roundtrip_and_oracle(oracle):
+    import torch
+    n = 4096 * 4 + 8192
+    L, R = oracle.synth_audio(n, 31337, True)
+    eng = _engine(F=512, T=64, stem_modes=(1, 1), oob_weights=(1.0, 0.25), max_tiles=1)
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    spec, _ = eng.stft(Ld, Rd, want_mag=False)
+    out = eng.istft(spec, None).cpu().numpy()               # all-ones mask
+    re, im = oracle.stft(L, R)
+    ref0 = oracle.istft(re, im)
+    peak = np.abs(ref0).max()
+    assert out.shape == (2, 2, ref0.shape[1])
+    assert np.abs(out[0] - ref0).max() <= 2e-6 * peak       # stem 0: oob weight 1 -> plain istft
+    # interior of the round trip reproduces the input (OLA gain 1): stftFix.c windows, SURVEY §4
+    x = np.stack([L, R])
+    assert np.abs(out[0][:, 4096:n - 4096] - x[:, 4096:n - 4096]).max() <= 1e-5
+    # stem 1: bins >= F scaled by 0.25 (mask is all-ones below F)
+    re2, im2 = re.copy(), im.copy()
+    re2[:, :, 512:2049] *= 0.25; im2[:, :, 512:2049] *= 0.25
+    ref1 = oracle.istft(re2, im2)
+    assert np.abs(out[1] - ref1).max() <= 2e-6 * peak
+    eng.close()
+
+
+def test_separate_end_to_end(oracle, coeffs):
+    """PCM -> stems against the oracle's stft -> processMT -> istft (main.c:776-785), 2 stems, ragged tail tile."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    n = 4096 * 24 + 8192                                     # 104 rows -> 1 full tile + 40-row tail
+    L, R = oracle.synth_audio(n, 777, True)
+    modes = (1, 0)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=2)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    out = eng.separate(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    re, im = oracle.stft(L, R)
+    for s in range(2):
+        r, i = re.copy(), im.copy()
+        oracle.process_spectrogram(coeffs(s), r, i, F, T, modes[s], oracle.VARIANT_VST, 0.1)
+        ref = oracle.istft(r, i)
+        peak = np.abs(ref).max()
+        assert _rel_rms(out[s], ref) <= 1e-4, "stem %d rel rms %g" % (s, _rel_rms(out[s], ref))
+        assert np.abs(out[s] - ref).max() <= 1e-4 * peak
+    eng.close()
