@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the separation hot path on N MI355X (one process per GPU).
+
+A "step" = one pass of PCM -> STFT -> |.| -> 4 U-Nets -> mask -> iSTFT over one batch of 64 spectrogram tiles
+(256 frames x 1024 bins, 4 stems, 44.1 kHz stereo, fp32): BASELINE.json configs[2], the 1-GPU configuration the
+metric is quoted on.  Inputs (PCM) and outputs (stems) are resident in HBM.  Multi-GPU is weak scaling: tiles are
+independent (main.c:455-495), every rank processes its own 64-tile batch, and the only collective is the RCCL
+broadcast of the weight blobs at start-up.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F, T, STEMS, TILES = 1024, 256, 4, 64
+FS, HOP = 44100.0, 1024
+FLOP_PER_PIXEL = 23264                      # per T-F pixel per sub-net, SURVEY §8d (sum of 2MNK over the 13 GEMMs)
+PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_TBS = 8.0
+# FLOP per launch and per instance (one tile of one stem) for every layer kernel, T=256 F=1024
+LAYER_FLOP = {}
+_enc = [(2, 16), (16, 32), (32, 64), (64, 128), (128, 256), (256, 512)]
+_dec = [(512, 256), (512, 128), (256, 64), (128, 32), (64, 16), (32, 1)]
+for i, (ci, co) in enumerate(_enc):
+    LAYER_FLOP["down%d" % (i + 1)] = 2 * co * ci * 25 * (T >> (i + 1)) * (F >> (i + 1))
+for i, (ci, co) in enumerate(_dec):
+    LAYER_FLOP["up%d" % (i + 1)] = 2 * co * ci * 25 * (T >> (6 - i)) * (F >> (6 - i))
+LAYER_FLOP["up7"] = 2 * 2 * 16 * T * F
+assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
+
+
+def synth_weights(stem, device):
+    """Random-init weights of the reference architecture, fp16-representable, spleeterCoeff field order."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(2024 + stem)
+    parts = []
+
+    def u(n, scale, off=0.0):
+        parts.append((off + scale * (torch.rand(n, generator=g) - 0.5)).half().float())
+    for i, (ci, co) in enumerate(_enc):
+        u(25 * ci * co, 2.0 * (6.0 / (25 * ci)) ** 0.5); u(co, 0.02)
+        if i < 5:
+            u(co, 0.2); u(co, 0.5, 1.0)
+    for ci, co in _dec:
+        u(25 * ci * co, 2.0 * (6.0 / (25 * ci / 4.0)) ** 0.5); u(co, 0.02); u(co, 0.2); u(co, 0.5, 1.0)
+    u(32, 2.0 * (6.0 / 16.0) ** 0.5); u(2, 0.02)
+    w = torch.cat(parts)
+    assert w.numel() == 9822725
+    return w.to(device)
+
+
+def cpu_baseline(sample_tiles=None):
+    """Reference CPU path (oracle/_ref: the reference's own C compiled from /root/reference, CPU_GEMM=1 naive GEMM)
+    on a bounded sample: tile-parallel like processMT (main.c:544-673) — one pthread-equivalent per tile, each running
+    the 4 sub-net forwards of its tile with the sequential GEMM — plus the reference stft/istft of the same span."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")          # tile-level parallelism only, as processMT does
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as O
+    flags = open("/proc/cpuinfo").read()
+    flavour = "avx2" if (" avx2 " in flags and " fma " in flags and O.ref_path("avx2")) else "exe"
+    kind = "reference"
+    if O.ref_path(flavour) is None:
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref not built"}
+    cores = min(os.cpu_count() or 1, 64)
+    ntiles = sample_tiles or cores
+    coeffs = [O.synth_coeff(s) for s in range(STEMS)]
+    n = ntiles * T * HOP
+    L, R = O.synth_audio(n, 777, True)
+    st = O.RefSTFT(cores=min(cores, 16), flavour=flavour)
+    t0 = time.time()
+    re, im = st.stft(L, R)
+    t_stft = time.time() - t0
+    mags = [O.magnitude_tile(re, im, j * T, T, F) for j in range(ntiles)]
+
+    def work(j):
+        out = []
+        for s in range(STEMS):
+            net = O.RefNet(coeffs[s], F, T, 1, flavour)
+            out.append(net(mags[j]))
+            net.close()
+        return out
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(ntiles)))
+    t_nn = time.time() - t0
+    t0 = time.time()
+    for s in range(STEMS):
+        st.istft(re, im)
+    t_istft = time.time() - t0
+    st.close()
+    frames = ntiles * T
+    total = t_stft + t_nn + t_istft
+    return {"value": frames / total, "unit": "frames/s", "x_realtime": frames * HOP / FS / total, "cores": cores, "kind": kind,
+            "sample": "%d tiles x %d stems (%d frames): stft %.2fs + nn %.2fs + istft %.2fs; %s build of the reference C "
+                      "(naive CPU_GEMM=1 GEMM, no MKL), one tile per thread as processMT" % (ntiles, STEMS, frames, t_stft, t_nn, t_istft, flavour)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=TILES)
+    ap.add_argument("--impl", default="mfma")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import spleeterrt_amd as srt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    eng = srt.Engine(F=F, T=T, stem_modes=(1,) * STEMS, oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST,
+                     max_tiles=a.tiles, impl=srt.IMPL_NAIVE if a.impl == "naive" else srt.IMPL_MFMA, device=dev)
+    # weights: rank 0 creates them, one RCCL broadcast per blob (the only collective on this path)
+    for s in range(STEMS):
+        w = synth_weights(s, dev) if rank == 0 else torch.empty(9822725, device=dev)
+        if world > 1:
+            dist.broadcast(w, 0)
+        eng.set_coeff(s, w)
+    n = a.tiles * T * HOP
+    g = torch.Generator(device=dev).manual_seed(777 + rank)
+    L = (torch.rand(n, device=dev, generator=g) - 0.5) * 0.2
+    R = (torch.rand(n, device=dev, generator=g) - 0.5) * 0.2
+    rows = eng.L.srtStftRows(n)
+    out = torch.empty((STEMS, 2, eng.L.srtIstftLength(rows)), device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        eng.separate(L, R, out)
+    sync()
+    eng.set_timing(True)                                    # HIP events on the engine's own stream, per kernel launch
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.separate(L, R, out)
+    sync()
+    dt = time.perf_counter() - t0
+    tim = eng.get_timing()
+    eng.set_timing(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        frames_total = rows * world * a.steps
+        fps = frames_total / dt
+        per = {}
+        for name, ms in tim:
+            per.setdefault(name, []).append(ms)
+        avg = {k: float(np.mean(v)) for k, v in per.items()}
+        inst = STEMS * a.tiles
+        nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP)
+        nn_flop = FLOP_PER_PIXEL * T * F * inst
+        dom = max((k for k in avg if k in LAYER_FLOP), key=lambda k: avg[k])
+        dom_tflops = LAYER_FLOP[dom] * inst / (avg[dom] * 1e-3) / 1e12
+        res = {
+            "metric": "x_realtime (4-stem separation, 44.1 kHz stereo, PCM->stems resident in HBM); frames_per_s alongside",
+            "value": fps * HOP / FS, "unit": "x real-time", "frames_per_s": fps,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "4-stem, fp32, batch=%d spectrogram tiles of %dx%d per GPU (BASELINE configs[2]); "
+                                   "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, rows, rows * HOP / FS),
+                       "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
+                       "impl": a.impl},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": LAYER_FLOP[dom] * inst, "avg_ms_per_launch": avg[dom]},
+            "nn_stack": {"achieved_tflops": nn_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "ms": nn_ms, "flop": nn_flop},
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
+            "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.cpu_tiles or None)
+            except Exception as ex:                          # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(res))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
