@@ -64,8 +64,10 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
 
 __device__ __forceinline__ const float* srt_src_channel(const SrtConvParams& p, int stem, int tile, int ch, size_t hw)
 {
-    return ch < p.CA ? p.srcA + stem * p.srcA_stem + tile * p.srcA_tile + (size_t)ch * hw
-                     : p.srcB + stem * p.srcB_stem + tile * p.srcB_tile + (size_t)(ch - p.CA) * hw;
+    const bool a = ch < p.CA;
+    const float* base = a ? p.srcA : p.srcB;
+    const size_t ss = a ? p.srcA_stem : p.srcB_stem, ts = a ? p.srcA_tile : p.srcB_tile;
+    return base + stem * ss + tile * ts + (size_t)(a ? ch : ch - p.CA) * hw;
 }
 
 // ------------------------------------------------------------------------------------------- naive kernels
@@ -203,7 +205,7 @@ template <int TW, int SW> struct EncPad {
 };
 
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
-__global__ void __launch_bounds__(256) srt_enc_mfma(const SrtConvParams p)
+__global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
@@ -232,26 +234,24 @@ __global__ void __launch_bounds__(256) srt_enc_mfma(const SrtConvParams p)
     float pin[NLD];
     float4 pw[NWL];
 
+    // Branch-free staging: every lane always issues its loads (address clamped to a valid element) and the
+    // out-of-range / padding lanes are zeroed by a select, so the loads pipeline instead of serialising.
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.0f;
-            if (e < NIN) {
-                const int col = e % PCOLS, r = (e / PCOLS) % PH, il = (e / (PCOLS * PH)) % NI, c = e / (PCOLS * PH * NI);
-                const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 + col - 1, tile = tile0 + il;
-                if (tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                    v = srt_src_channel(p, stem, tile, c0 + c, hw)[(size_t)gy * p.W + gx];
-            }
-            pin[i] = v;
+            const int e = min(tid + i * 256, NIN - 1);
+            const int col = e % PCOLS, ru = e / PCOLS, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+            const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 + col - 1, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+            const float v = src[ok ? (size_t)gy * p.W + gx : 0];
+            pin[i] = ok ? v : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
-            const int e = tid + i * 256;
-            if (e < NW4) {
-                const int m4 = e % (BM / 4), row = e / (BM / 4);
-                pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
-            }
+            const int e = min(tid + i * 256, NW4 - 1);
+            const int m4 = e % (BM / 4), row = e / (BM / 4);
+            pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
         }
     };
     auto store_chunk = [&]() {
@@ -314,27 +314,35 @@ __global__ void __launch_bounds__(256) srt_enc_mfma(const SrtConvParams p)
         }
     }
 
-    // epilogue: lane holds pixel l31 of each sub-tile and 16 output channels per accumulator
+    // epilogue: lane holds pixel l31 of each sub-tile and 16 output channels per accumulator.
+    // Per-channel constants are fetched once, unconditionally (clamped index), so the loads pipeline.
     const float* bias = p.bias + stem * p.coeff_stem;
-    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : nullptr;
-    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : nullptr;
+    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : bias;
+    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : bias;
+    const bool hasBn = p.bnScale != nullptr;
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-        const int s = wn * NR + nr;
-        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
-        const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
-        if (tile >= p.ntiles || oy >= Ho || ox >= Wo) continue;
-        const size_t obase = stem * p.out_stem + tile * p.out_tile + (size_t)oy * Wo + ox;
+    for (int mr = 0; mr < MR; ++mr) {
+        float bi[16], sc[16], sf[16];
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1);
+            bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int s = wn * NR + nr;
+            const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+            const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+            const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
+            const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.Cout) {
-                    const float v = acc[mr][nr][r] + bias[m];
+                if (pix_ok && m < p.Cout) {
+                    const float v = acc[mr][nr][r] + bi[r];
                     p.outRaw[obase + (size_t)m * ohw] = v;
-                    if (scale) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, scale[m], shift[m], p.act, p.variant);
+                    if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], p.act, p.variant);
                 }
             }
         }
@@ -345,7 +353,7 @@ __global__ void __launch_bounds__(256) srt_enc_mfma(const SrtConvParams p)
 // Tile is expressed in INPUT-resolution pixels (a,b); the workgroup produces the 2TH x 2TW output patch as four
 // parity-class accumulators.  tap (ky,kx) -> class (py,px) = ((ky+1)&1, (kx+1)&1), input shift dy = (py+1-ky)/2.
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
-__global__ void __launch_bounds__(256) srt_dec_mfma(const SrtConvParams p)
+__global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
@@ -371,26 +379,22 @@ __global__ void __launch_bounds__(256) srt_dec_mfma(const SrtConvParams p)
     float pin[NLD];
     float4 pw[NWL];
 
-    auto load_chunk = [&](int c0) {
+    auto load_chunk = [&](int c0) {              // branch-free, see srt_enc_mfma
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.0f;
-            if (e < NIN) {
-                const int col = e % PC, r = (e / PC) % PH, il = (e / (PC * PH)) % NI, c = e / (PC * PH * NI);
-                const int gy = ty0 + r - 1, gx = tx0 + col - 1, tile = tile0 + il;
-                if (tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                    v = srt_src_channel(p, stem, tile, c0 + c, hw)[(size_t)gy * p.W + gx];
-            }
-            pin[i] = v;
+            const int e = min(tid + i * 256, NIN - 1);
+            const int col = e % PC, ru = e / PC, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+            const int gy = ty0 + r - 1, gx = tx0 + col - 1, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+            const float v = src[ok ? (size_t)gy * p.W + gx : 0];
+            pin[i] = ok ? v : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
-            const int e = tid + i * 256;
-            if (e < NW4) {
-                const int m4 = e % (BM / 4), row = e / (BM / 4);
-                pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
-            }
+            const int e = min(tid + i * 256, NW4 - 1);
+            const int m4 = e % (BM / 4), row = e / (BM / 4);
+            pw[i] = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + m0 + m4 * 4);
         }
     };
     auto store_chunk = [&]() {
@@ -463,32 +467,110 @@ __global__ void __launch_bounds__(256) srt_dec_mfma(const SrtConvParams p)
     }
 
     const float* bias = p.bias + stem * p.coeff_stem;
-    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : nullptr;
-    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : nullptr;
+    const float* scale = p.bnScale + stem * p.coeff_stem;
+    const float* shift = p.bnShift + stem * p.coeff_stem;
     const int Ho = p.H << 1, Wo = p.W << 1;
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-        const int s = wn * NR + nr;
-        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
-        const int a = ty0 + sy * SH + l31 / SW, b = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
-        if (tile >= p.ntiles || a >= p.H || b >= p.W) continue;
-        const size_t obase = stem * p.out_stem + tile * p.out_tile + (size_t)(2 * a) * Wo + 2 * b;
+    for (int mr = 0; mr < MR; ++mr) {
+        float bi[16], sc[16], sf[16];
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1);
+            bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int s = wn * NR + nr;
+            const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+            const int a = ty0 + sy * SH + l31 / SW, b = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+            const bool pix_ok = tile < p.ntiles && a < p.H && b < p.W;
+            const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)(2 * a) * Wo + 2 * b : 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.Cout) {
-                    const float bi = bias[m], sc = scale[m], sf = shift[m];
+                if (pix_ok && m < p.Cout) {
 #pragma unroll
                     for (int py = 0; py < 2; ++py) {
                         float2 v;
-                        v.x = srt_dec_epilogue(acc[py * 2 + 0][mr][nr][r], bi, sc, sf, p.act, p.variant);
-                        v.y = srt_dec_epilogue(acc[py * 2 + 1][mr][nr][r], bi, sc, sf, p.act, p.variant);
+                        v.x = srt_dec_epilogue(acc[py * 2 + 0][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                        v.y = srt_dec_epilogue(acc[py * 2 + 1][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
                         *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
                     }
                 }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------- up6 (Cout = 1)
+// A 1-channel transposed conv has no M dimension for the parity-class form, so this layer uses the GEMM form
+// on the matrix cores: col[tap][pix] = sum_ci w[ci][tap] * x[ci][pix]  (M = 25 taps padded to 32, K = Cin, N = pixels
+// of the input tile + 1-pixel halo), the 25 x N result goes to LDS only, and each input pixel's 2x2 output quad then
+// GATHERS its taps from LDS (no scatter, no atomics) with bias -> act -> BN fused.  B operands come straight from
+// global memory (every element feeds exactly one MFMA, so LDS staging would buy nothing).
+template <int TH, int TW, int CIN>
+__global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
+{
+    constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
+    __shared__ float s_col[25 * NPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tilesX = (p.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
+    const int stem = blockIdx.z / p.ntiles, tile = blockIdx.z % p.ntiles;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* w = p.wraw + stem * p.coeff_stem;               // [Cin][1][25]
+    float a[CIN / 2];
+#pragma unroll
+    for (int cp = 0; cp < CIN / 2; ++cp) {
+        const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
+        a[cp] = l31 < 25 ? v : 0.0f;
+    }
+    for (int sub = wave; sub < NSUB; sub += 4) {
+        const int pix = sub * 32 + l31, pr = pix / PW, pc = pix % PW;
+        const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
+        const bool ok = pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const size_t off = ok ? (size_t)gy * p.W + gx : 0;
+        float b[CIN / 2];
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) {
+            const float v = srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
+            b[cp] = ok ? v : 0.0f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (tap < 25) s_col[tap * NPAD + pix] = acc[r];
+        }
+    }
+    __syncthreads();
+    const float bi = p.bias[stem * p.coeff_stem], sc = p.bnScale[stem * p.coeff_stem], sf = p.bnShift[stem * p.coeff_stem];
+    const int Wo = p.W << 1;
+    float* out = p.outAct + stem * p.out_stem + tile * p.out_tile;
+    for (int q = tid; q < TH * TW; q += 256) {
+        const int a0 = q / TW, b0 = q % TW;
+        float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {                      // ascending (ky,kx): the reference's col2im order
+            const int ky = tap / 5, kx = tap % 5;
+            const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+            o[py * 2 + px] += s_col[tap * NPAD + (a0 + 1 + dy) * PW + (b0 + 1 + dx)];
+        }
+        const int ga = ty0 + a0, gb = tx0 + b0;
+        if (ga < p.H && gb < p.W) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float2 v;
+                v.x = srt_dec_epilogue(o[py * 2 + 0], bi, sc, sf, p.act, p.variant);
+                v.y = srt_dec_epilogue(o[py * 2 + 1], bi, sc, sf, p.act, p.variant);
+                *reinterpret_cast<float2*>(out + (size_t)(2 * ga + py) * Wo + 2 * gb) = v;
             }
         }
     }
@@ -536,7 +618,14 @@ int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
 
 int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
-    if (impl != 0 || p.Cout < 16) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
+    if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
+    if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
+        constexpr int TH = 16, TW = 32;
+        dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), 1, p.nstems * p.ntiles);
+        hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), grid, dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (p.Cout < 16) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout <= 32) return launch_dec_cfg<32, 1, 32, 2, 4, 1, 4>(p, s);                    // up4/up5: 4 rows x 64 cols
     if (p.W >= 32) return launch_dec_cfg<64, 2, 32, 1, 4, 1, 4>(p, s);                       // up2/up3: 4 rows x 32 cols
     return launch_dec_cfg<64, 2, 16, 1, 2, 2, 4>(p, s);                                      // up1: 2 instances of 4x16
