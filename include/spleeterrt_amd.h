@@ -70,6 +70,10 @@ SRT_API int  srtStft(srt_engine *e, const float *d_L, const float *d_R, size_t n
 SRT_API int  srtIstft(srt_engine *e, const float *d_spec, size_t rows, const float *d_masks, float *d_out);
 /* whole hot path, everything in HBM: PCM -> STFT -> |.| -> U-Nets -> mask -> iSTFT.  d_out as in srtIstft. */
 SRT_API int  srtSeparate(srt_engine *e, const float *d_L, const float *d_R, size_t n, float *d_out);
+/* Explicit-geometry forms for streams cut into tile ranges (shards / chunks): transform `frames` frames (frame i starts at
+ * sample i*1024, zero padded past n) and emit `rows` >= frames rows (the extra rows are zero, as the reference's calloc). */
+SRT_API int  srtStftEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_spec, float *d_mag);
+SRT_API int  srtSeparateEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_out);
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */

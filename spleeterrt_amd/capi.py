@@ -48,6 +48,8 @@ def load_library():
     L.srtStft.argtypes = [vp, f32p, f32p, C.c_size_t, f32p, f32p]
     L.srtIstft.argtypes = [vp, f32p, C.c_size_t, f32p, f32p]
     L.srtSeparate.argtypes = [vp, f32p, f32p, C.c_size_t, f32p]
+    L.srtStftEx.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p]
+    L.srtSeparateEx.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
     L.srtCopyTensor.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
     L.srtSetTiming.argtypes = [vp, C.c_int]
     L.srtGetTiming.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
@@ -155,6 +157,14 @@ class Engine:
         if out is None:
             out = t.empty((self.S, 2, self.L.srtIstftLength(rows)), device=self.device, dtype=t.float32)
         self._chk(self.L.srtSeparate(self.h, _ptr(L), _ptr(R), n, _ptr(out)))
+        return out
+
+    def separate_ex(self, L, R, frames, rows, out=None):
+        """explicit-geometry form used by spleeterrt_amd.stream for tile ranges of a longer stream"""
+        t = self.torch
+        if out is None:
+            out = t.empty((self.S, 2, self.L.srtIstftLength(rows)), device=self.device, dtype=t.float32)
+        self._chk(self.L.srtSeparateEx(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), L.numel(), frames, rows, _ptr(out)))
         return out
 
     # ---- debug / measurement

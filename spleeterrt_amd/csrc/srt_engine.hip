@@ -60,7 +60,7 @@ struct srt_engine {
     // DSP
     float *preWin, *postWin; float2* twiddle;
     float2* spec; float* mag; float* masks; float* frames;
-    size_t rows_cap;
+    size_t rows_cap, frames_rows;
     int last_ntiles;
     // timing
     bool timing; std::vector<TimingEntry> tlog;
@@ -130,7 +130,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     EALLOC(e->spec, 2 * 2 * e->rows_cap * SRT_SPEC_LD);
     EALLOC(e->mag, NT * 2 * HW);
     EALLOC(e->masks, S * NT * 2 * HW);
-    EALLOC(e->frames, S * 2 * e->rows_cap * SRT_FFT);
+    e->frames_rows = 0;                                 // windowed-frame scratch is allocated on first use (ensure_frames)
 #undef EALLOC
     // tables: same formulas and float rounding as InitSTFT (stftFix.c:302-313)
     std::vector<float> pre(SRT_FFT), post(SRT_FFT), tw(2 * SRT_FFT), sig(1026);
@@ -275,17 +275,28 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
 
 static SrtDspTables tables_of(const srt_engine* e) { SrtDspTables t; t.preWin = e->preWin; t.postWin = e->postWin; t.twiddle = e->twiddle; return t; }
 
-int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_spec, float* d_mag)
+// grow-only scratch for the windowed time frames written by the inverse FFT kernel
+static int ensure_frames(srt_engine* e, size_t rows)
+{
+    if (rows <= e->frames_rows) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->frames) hipFree(e->frames);
+    e->frames = nullptr; e->frames_rows = 0;
+    HIPCHK(hipMalloc((void**)&e->frames, (size_t)e->cfg.n_stems * 2 * rows * SRT_FFT * sizeof(float)));
+    e->frames_rows = rows;
+    return 0;
+}
+
+int srtStftEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_spec, float* d_mag)
 {
     if (!e || !d_L || !d_R || !d_spec) return fail(-1, "srtStft: null argument");
-    if (n < SRT_FFT) return fail(-1, "srtStft: need at least 4096 samples");          // the reference underflows here (stftFix.c:378)
-    const size_t rows = srtStftRows(n);
+    if (rows < 1 || frames > rows) return fail(-1, "srtStft: need 1 <= frames <= rows");
     const int T = e->cfg.T;
     const size_t ntiles = (rows + T - 1) / T;
-    if (d_mag && ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtStft: signal longer than max_tiles * T frames");
+    if (d_mag && ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtStft: more than max_tiles * T rows");
     SrtStftParams p; memset(&p, 0, sizeof p);
     p.L = d_L; p.R = d_R; p.nsamples = n;
-    p.frames_computed = (int)srtStftFrames(n);
+    p.frames_computed = (int)frames;
     p.rows_total = (int)rows;
     p.spec = (float2*)d_spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
     p.mag = nullptr; p.T = T; p.F = e->cfg.F; p.tab = tables_of(e);
@@ -299,11 +310,20 @@ int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* 
     return 0;
 }
 
+int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_spec, float* d_mag)
+{
+    if (n < SRT_FFT) return fail(-1, "srtStft: need at least 4096 samples");          // the reference underflows here (stftFix.c:378)
+    return srtStftEx(e, d_L, d_R, n, srtStftFrames(n), srtStftRows(n), d_spec, d_mag);
+}
+
 int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out)
 {
     if (!e || !d_spec || !d_out) return fail(-1, "srtIstft: null argument");
-    if (rows < 1 || rows > e->rows_cap) return fail(-1, "srtIstft: rows exceed max_tiles * T");
+    if (rows < 1) return fail(-1, "srtIstft: no rows");
     const int T = e->cfg.T;
+    if (d_masks && (rows + T - 1) / T > (size_t)e->cfg.max_tiles) return fail(-1, "srtIstft: rows exceed max_tiles * T");
+    int rc = ensure_frames(e, rows);
+    if (rc) return rc;
     SrtIstftParams p; memset(&p, 0, sizeof p);
     p.spec = (const float2*)d_spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
     p.frames = (int)rows; p.masks = d_masks; p.nstems = e->cfg.n_stems; p.ntiles = (int)((rows + T - 1) / T);
@@ -315,18 +335,23 @@ int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_mas
     return 0;
 }
 
-int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_out)
+int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_out)
 {
     if (!e) return fail(-1, "srtSeparate: null engine");
-    const size_t rows = srtStftRows(n);
     const int T = e->cfg.T;
     const size_t ntiles = (rows + T - 1) / T;
     if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparate: signal longer than max_tiles * T frames");
-    int rc = srtStft(e, d_L, d_R, n, (float*)e->spec, e->mag);
+    int rc = srtStftEx(e, d_L, d_R, n, frames, rows, (float*)e->spec, e->mag);
     if (rc) return rc;
     rc = srtForward(e, e->mag, (int)ntiles, e->masks);
     if (rc) return rc;
     return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+}
+
+int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_out)
+{
+    if (n < SRT_FFT) return fail(-1, "srtSeparate: need at least 4096 samples");
+    return srtSeparateEx(e, d_L, d_R, n, srtStftFrames(n), srtStftRows(n), d_out);
 }
 
 int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_dst, size_t max_floats)

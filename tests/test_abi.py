@@ -1,0 +1,72 @@
+"""CPU tests: the C-ABI library loads without a GPU, exports every symbol the public headers declare, answers the
+pure-host geometry calls, and refuses (loudly, with an error code) to create an engine without a HIP device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from spleeterrt_amd import build as b
+    so = b.build(verbose=False)
+    import spleeterrt_amd
+    return spleeterrt_amd.load_library(), so
+
+
+def _declared():
+    names = set()
+    for h in os.listdir(INC):
+        txt = "\n".join(ln for ln in open(os.path.join(INC, h)).read().splitlines() if not ln.lstrip().startswith("#"))
+        names |= set(re.findall(r"(?:SRT_API|SPLEETER_API|STFT_API)\s+[\w\s\*]*?\b(\w+)\s*\(", txt))
+    return names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    L, so = lib
+    declared = _declared()
+    assert {"srtCreate", "srtForward", "srtSeparate", "initSpleeter", "processSpleeter", "getMaskPtr", "InitSTFT", "stft", "istft"} <= declared
+    exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines()}
+    assert declared <= exported, declared - exported
+    # and nothing private leaks: only the three API families are visible
+    assert all(n.startswith("srt") or n in declared for n in exported if not n.startswith("_")), exported
+
+
+def test_sizes_and_geometry(lib):
+    L, _ = lib
+    L.getCoeffSize.restype = C.c_size_t
+    assert L.srtCoeffBytes() == L.getCoeffSize() == 39290900
+    # main.c:762-766 padding: n = 4096*ceil(441000/4096) + 8192 -> 440 rows, 437 transformed frames
+    n = 4096 * 108 + 8192
+    assert L.srtStftRows(n) == 440 and L.srtStftFrames(n) == 437 and L.srtIstftLength(440) == 440 * 1024 + 3072
+    assert L.srtStftFrames(4096) == 1 and L.srtStftRows(4097) == 5
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import spleeterrt_amd as srt
+    with pytest.raises(srt.EngineError):
+        srt.Engine()
+    from spleeterrt_amd.capi import _Config
+    cfg = _Config()
+    cfg.F, cfg.T, cfg.n_stems, cfg.max_tiles = 512, 64, 1, 1
+    h = C.c_void_p()
+    L, _ = lib
+    assert L.srtCreate(C.byref(cfg), None, C.byref(h)) < 0 and b"no HIP device" in L.srtLastError()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "spleeterrt_amd")
+    for dp, _, files in os.walk(os.path.join(pkg, "csrc")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(dp, f)).read().lower(), f
+    for f in ("capi.py", "build.py", "stream.py", "__init__.py"):
+        txt = open(os.path.join(pkg, f)).read()
+        assert "pyoracle" not in txt and "liboracle" not in txt

@@ -1,0 +1,75 @@
+"""Drop-in proof (GPU): the SAME plain-C host program (host/offline_main.c, written only against the reference's
+spleeter.h + stftFix.h API) is linked once against libspleeterrt_amd.so and once against the real reference
+(oracle/_ref) and must produce the same stems.  Also exercises the Python view of the same C entry points."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "host")
+
+
+def _rel_rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory, oracle):
+    d = tmp_path_factory.mktemp("dropin")
+    # fp16 container with 2 sub-nets: net[0] drum (ELU), net[1] vocal (LeakyReLU/ReLU)  (main.c:759-760)
+    h = np.concatenate([oracle.synth_coeff_fp16(1), oracle.synth_coeff_fp16(0)])
+    h.tofile(d / "weights.f16")
+    n = 44100 * 3 + 123
+    L, R = oracle.synth_audio(n, 777, True)
+    np.stack([L, R], 1).astype(np.float32).tofile(d / "in.f32")
+    return d
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_same_host_program_two_backends(workdir, oracle, stems):
+    amd, ref = os.path.join(HOST, "offline_amd"), os.path.join(HOST, "offline_ref")
+    if not os.path.exists(amd):
+        subprocess.check_call(["make", "-s", "-C", HOST, "offline_amd"])
+    if not os.path.exists(ref) or oracle.ref_path("exe") is None:
+        pytest.skip("reference build (oracle/_ref, host/offline_ref) not present")
+    env = dict(os.environ, SPLEETERRT_VARIANT="exe")
+    for exe, tag in ((amd, "amd"), (ref, "ref")):
+        subprocess.check_call([exe, "64", "512", str(stems), str(workdir / "weights.f16"), str(workdir / "in.f32"),
+                               str(workdir / ("out%d_%s" % (stems, tag)))], env=env)
+    names = ["Vocal", "Accompaniment"] + (["Drum"] if stems == 3 else [])
+    for nm in names:
+        a = np.fromfile(workdir / ("out%d_amd_%s.f32" % (stems, nm)), np.float32)
+        r = np.fromfile(workdir / ("out%d_ref_%s.f32" % (stems, nm)), np.float32)
+        assert a.shape == r.shape and a.size == 2 * (44100 * 3 + 123)
+        assert _rel_rms(a, r) <= 1e-4, "%s: rel rms %g" % (nm, _rel_rms(a, r))
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max()
+
+
+def test_tile_api_via_ctypes(oracle, coeffs):
+    """initSpleeter / processSpleeter / getMaskPtr with host pointers, y aliasing the mask buffer (main.c:453,472)."""
+    import spleeterrt_amd
+    L = spleeterrt_amd.load_library()
+    os.environ["SPLEETERRT_VARIANT"] = "vst"
+    T, F = 64, 512
+    L.allocateSpleeterStr.restype = C.c_void_p
+    nn = C.c_void_p(L.allocateSpleeterStr())
+    c = np.ascontiguousarray(coeffs(1))
+    L.initSpleeter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+    L.initSpleeter(nn, F, T, 1, c.ctypes.data)
+    mask = C.POINTER(C.c_float)()
+    L.getMaskPtr.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float))]
+    L.getMaskPtr(nn, C.byref(mask))
+    x = np.abs(oracle.lcg(8, 2 * T * F, 6.0)).reshape(2, T, F).astype(np.float32)
+    L.processSpleeter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.processSpleeter(nn, x.ctypes.data, mask)
+    y = np.ctypeslib.as_array(mask, shape=(2, T, F)).copy()
+    assert np.abs(y - oracle.forward(c, x, 1, oracle.VARIANT_VST)).max() <= 2e-4
+    L.freeSpleeter.argtypes = [C.c_void_p]
+    L.freeSpleeter(nn)
+    C.CDLL(None).free.argtypes = [C.c_void_p]
+    C.CDLL(None).free(nn)
+    os.environ.pop("SPLEETERRT_VARIANT")
