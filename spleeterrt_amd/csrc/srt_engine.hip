@@ -54,6 +54,8 @@ struct srt_engine {
     float* coeff_all;                                  // [n_stems][SRT_COEFF_STRIDE]
     float* wpack_down[6]; float* wpack_up[6];          // per layer: [n_stems][Cin*25*CP]
     size_t wpack_down_stem[6], wpack_up_stem[6];
+    float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
+    float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* act[5]; float* up[6];
     size_t raw_tile[6], act_tile[5], up_tile[6];       // floats per instance
@@ -87,6 +89,8 @@ struct TimerScope {
 static void free_all(srt_engine* e)
 {
     if (e->coeff_all) hipFree(e->coeff_all);
+    if (e->wpack2_d1) hipFree(e->wpack2_d1);
+    if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
     for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act[i]) hipFree(e->act[i]); }
     void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->mag, e->masks, e->frames };
@@ -103,7 +107,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "srtCreate: no HIP device (this library has no CPU path)");
     srt_engine* e = new srt_engine();
-    e->coeff_all = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
+    e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->act, 0, sizeof e->act); memset(e->up, 0, sizeof e->up);
     e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->mag = e->masks = e->frames = nullptr;
@@ -112,6 +116,8 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     const size_t S = cfg->n_stems, NT = cfg->max_tiles, HW = (size_t)cfg->T * cfg->F;
 #define EALLOC(ptr, nfloats) do { if (hipMalloc((void**)&(ptr), (nfloats) * sizeof(float)) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); } } while (0)
     EALLOC(e->coeff_all, S * SRT_COEFF_STRIDE);
+    EALLOC(e->wpack2_d1, (size_t)2 * 25 * 128);
+    EALLOC(e->wpack2_u5, S * 64 * 15 * 32);
     for (int i = 0; i < 6; ++i) {
         e->wpack_down_stem[i] = (size_t)e->lo.down[i].cin * 25 * e->lo.down[i].cp;
         e->wpack_up_stem[i] = (size_t)e->lo.up[i].cin * 25 * e->lo.up[i].cp;
@@ -169,6 +175,8 @@ static int pack_stem(srt_engine* e, int stem)
         if (srt_launch_pack_enc(c + D.w, e->wpack_down[i] + stem * e->wpack_down_stem[i], D.cin, D.cout, D.cp, e->stream)) return fail(-2, "pack launch failed");
         if (srt_launch_pack_dec(c + U.w, e->wpack_up[i] + stem * e->wpack_up_stem[i], U.cin, U.cout, U.cp, e->stream)) return fail(-2, "pack launch failed");
     }
+    if (srt_launch_pack_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack2_u5 + (size_t)stem * 64 * 15 * 32, 64, 16, e->stream))
+        return fail(-2, "pack launch failed");
     e->have_coeff[stem] = true;
     return 0;
 }
@@ -231,9 +239,15 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             p.outAct = i < 5 ? e->act[i] + (size_t)s0 * ntiles * e->act_tile[i] : nullptr;
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.variant = e->cfg.variant;
+            if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
+                p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
+                if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
+            }
             snprintf(nm, sizeof nm, "down%d", i + 1);
             TimerScope ts(e, nm);
-            if (srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
+            int rc2 = e->cfg.impl == SRT_IMPL_MFMA ? srt_launch_enc2(p, e->stream) : 1;
+            if (rc2 < 0) return fail(-2, "encoder launch failed");
+            if (rc2 == 1 && srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
         }
         for (int i = 0; i < 6; ++i) {                                           // decoder (spleeter.c:239-294)
             const LayerOff& L = e->lo.up[i];
@@ -254,9 +268,12 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             p.outAct = e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
             p.out_stem = (size_t)ntiles * e->up_tile[i]; p.out_tile = e->up_tile[i];
             p.act = actD; p.variant = e->cfg.variant;
+            if (i == 4) { p.wpack2 = e->wpack2_u5 + (size_t)s0 * 64 * 15 * 32; p.wpack2_stem = 64 * 15 * 32; p.CP2 = 32; }
             snprintf(nm, sizeof nm, "up%d", i + 1);
             TimerScope ts(e, nm);
-            if (srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
+            int rc2 = e->cfg.impl == SRT_IMPL_MFMA ? srt_launch_dec2(p, e->stream) : 1;
+            if (rc2 < 0) return fail(-2, "decoder launch failed");
+            if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
         }
         {                                                                       // head (spleeter.c:295-300)
             SrtHeadParams h; memset(&h, 0, sizeof h);

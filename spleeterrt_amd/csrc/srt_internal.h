@@ -31,6 +31,11 @@ struct SrtConvParams {
     const float* wpack;   // GEMM layout [Cin][25][CP], zero padded to CP output channels
     size_t wpack_stem;
     int CP;
+    // stacked-M weight layouts (srt_nn2.hip): fill otherwise half-empty 32-row MFMA tiles of the Cout = 16 layers
+    const float* wpack2;  // down1: [Cin][25][CP2] rows = stem*16+co over the `stack` stems of this launch (shared input);
+                          // up5:   [Cin][15][32] per stem, rows = px*16+co, 15 = (ky, dx) pairs (two x-parity classes per tile)
+    size_t wpack2_stem;
+    int CP2, stack;
     float* outRaw;        // encoder: conv+bias (skip tensor); decoder: unused
     float* outAct;        // encoder: act(bn(v)); decoder: bn(act(v))
     size_t out_stem, out_tile;
@@ -51,6 +56,11 @@ int  srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_head(const SrtHeadParams& p, hipStream_t s);
 int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
+// v2 kernels (srt_nn2.hip): return 1 when the layer geometry is not covered (caller falls back to the v1 kernels)
+int  srt_launch_enc2(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_dec2(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_pack_stemstack(const float* coeff_w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s);
+int  srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, hipStream_t s);
 int  srt_set_sigmoid_table(const float* tbl1026);
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);
 

@@ -14,9 +14,7 @@
 //     deterministic, epilogue (bias -> act -> BN) fused, the skip concat is two source pointers.
 //   * global->LDS staging is register-prefetched one K-chunk ahead so HBM/L2 latency hides under the MFMAs.
 // The naive kernels are a bit-simple cross-check path (SRT_IMPL_NAIVE) and serve layers not yet on MFMA.
-#include "srt_internal.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "srt_device.h"
 
 // ------------------------------------------------------------------------------------------- activations
 __device__ float g_sigmoid_tbl[1026];
@@ -26,16 +24,7 @@ int srt_set_sigmoid_table(const float* tbl1026)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sigmoid_tbl), tbl1026, 1026 * sizeof(float)) == hipSuccess ? 0 : -1;
 }
 
-// The epilogue math keeps the reference's operation order with contraction off, so the only difference
-// from the CPU path is the summation order inside the dot products.
 #pragma clang fp contract(off)
-__device__ __forceinline__ float srt_act(float x, int kind, int variant)
-{
-    if (kind == SRT_ACT_LEAKY) return x >= 0.0f ? x : 0.2f * x;          // Executable/spleeter.c:43-46
-    if (kind == SRT_ACT_RELU) return x >= 0.0f ? x : 0.0f;               // :47-50
-    if (variant == 0 && x < -15.0f) return -1.0f;                        // :51-56 (VST flavour has no clamp)
-    return x >= 0.0f ? x : expf(x) - 1.0f;
-}
 __device__ __forceinline__ float srt_sigmoid(float x, int variant)
 {
     if (variant == 0) {                                                  // LUT, Executable/spleeter.c:30-42
@@ -51,24 +40,7 @@ __device__ __forceinline__ float srt_sigmoid(float x, int variant)
     float z = expf(x);
     return z / (1.0f + z);
 }
-__device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, int act, int variant)
-{
-    return srt_act(scale * v + shift, act, variant);                     // spleeter.c:188: act(bn[C+s]*v + bn[s])
-}
-__device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float scale, float shift, int act, int variant)
-{
-    float v = srt_act(acc + bias, act, variant);                         // spleeter.c:244-245: activation BEFORE BN
-    return scale * v + shift;
-}
 #pragma clang fp contract(fast)
-
-__device__ __forceinline__ const float* srt_src_channel(const SrtConvParams& p, int stem, int tile, int ch, size_t hw)
-{
-    const bool a = ch < p.CA;
-    const float* base = a ? p.srcA : p.srcB;
-    const size_t ss = a ? p.srcA_stem : p.srcB_stem, ts = a ? p.srcA_tile : p.srcB_tile;
-    return base + stem * ss + tile * ts + (size_t)(a ? ch : ch - p.CA) * hw;
-}
 
 // ------------------------------------------------------------------------------------------- naive kernels
 __global__ void srt_enc_naive(const SrtConvParams p)

@@ -1,0 +1,431 @@
+// srt_nn2.hip — second-generation MFMA conv kernels (same math as srt_nn.hip's srt_enc_mfma / srt_dec_mfma):
+//   * weight slabs arrive by LDS-DMA (global_load_lds_dwordx4) into a double-buffered LDS ring: no VGPRs, no ds_write pass;
+//   * input patches are staged as aligned float4 row segments (4x fewer address computations, ds_write_b64/b128);
+//   * Cout = 16 layers fill the otherwise half-empty 32-row MFMA tile:
+//       down1: the stems of a launch share their input, so M = (stem, co)            ("stem-stacked")
+//       up5  : the two x-parity classes of a tap row share their B operand, M = (px, co) and 15 instead of 25
+//              tap-MFMAs per channel pair                                            ("class-stacked")
+// Requires W % 4 == 0 (every level of T,F multiples of 128; otherwise the v1 kernels run).
+#include "srt_device.h"
+
+// ------------------------------------------------------------------------------------------- stacked weight packing
+// down1: wp2[(ci*25+tap)*CP2 + stem*Cout + co] = w_stem[co][ci][tap]
+__global__ void srt_pack_stemstack_kernel(const float* __restrict__ w0, size_t coeff_stem, int nstems, float* __restrict__ wp2, int Cin, int Cout, int CP2)
+{
+    const int total = Cin * 25 * CP2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int m = e % CP2, tap = (e / CP2) % 25, ci = e / (CP2 * 25);
+        const int st = m / Cout, co = m % Cout;
+        wp2[e] = st < nstems ? w0[st * coeff_stem + ((size_t)co * Cin + ci) * 25 + tap] : 0.0f;
+    }
+}
+int srt_launch_pack_stemstack(const float* w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_pack_stemstack_kernel, dim3(16), dim3(256), 0, s, w0, coeff_stem, nstems, wp2, Cin, Cout, CP2);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// up5: wp2[(ci*15 + ky*3 + (dx+1))*32 + px*16 + co] = w[ci][co][ky][kx],  kx = px + 1 - 2*dx  (zero when kx is outside 0..4)
+__global__ void srt_pack_classstack_kernel(const float* __restrict__ w, float* __restrict__ wp2, int Cin, int Cout)
+{
+    const int total = Cin * 15 * 32;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int row = e % 32, t = (e / 32) % 15, ci = e / (32 * 15);
+        const int px = row / 16, co = row % 16, ky = t / 3, dx = t % 3 - 1;
+        const int kx = px + 1 - 2 * dx;
+        wp2[e] = (kx >= 0 && kx < 5 && co < Cout) ? w[((size_t)ci * Cout + co) * 25 + ky * 5 + kx] : 0.0f;
+    }
+}
+int srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_pack_classstack_kernel, dim3(64), dim3(256), 0, s, w, wp2, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------- LDS-DMA helper
+// One wave-instruction moves 64 lanes x 16 B = 1 KiB: LDS destination = wave-uniform base + lane*16, global source per lane.
+__device__ __forceinline__ void srt_dma16(const float* gsrc, float* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// slab = NROWS rows of BM floats (row r at wp + r*rowStride); padded up to a whole number of 1-KiB pieces
+template <int NROWS, int BM>
+__device__ __forceinline__ void srt_dma_slab(const float* wp, size_t rowStride, float* lds, int wave, int lane)
+{
+    constexpr int RPI = 256 / BM;                       // rows per wave-instruction
+    constexpr int NPIECE = (NROWS + RPI - 1) / RPI;
+#pragma unroll
+    for (int i = 0; i < (NPIECE + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;                 // wave-uniform
+        if (piece < NPIECE) {
+            const int row = min(piece * RPI + lane / (BM / 4), NROWS - 1);
+            srt_dma16(wp + (size_t)row * rowStride + (lane % (BM / 4)) * 4, lds + piece * 256);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- encoder v2
+template <int TW, int SW> struct Enc2Pad {
+    static constexpr int base = TW + 4;                 // halves per parity plane of a staged row
+    // even, >= base, and (for sub-tiles with several rows) 2*ROWS = 4*PWH == 16 or 8 (mod 32) so rows hit disjoint banks
+    static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
+};
+
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK>
+__global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
+    static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
+    constexpr int PH = 2 * TH + 3, RW4 = (2 * TW + 8) / 4;
+    constexpr int PWH = Enc2Pad<TW, SW>::value;
+    static_assert(PWH >= TW + 4 && PWH % 2 == 0, "pad");
+    constexpr int ROWS = 2 * PWH, INS = PH * ROWS, CHS = NI * INS;
+    constexpr int NF4 = KC * NI * PH * RW4, NLD = (NF4 + 255) / 256;
+    constexpr int WROWS = KC * 25, WSLAB = (WROWS * BM + 255) / 256 * 256;
+
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
+    float* s_in = s_mem;
+    float* s_w = s_mem + KC * CHS;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int tilesX = (Wo + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
+    const int m0 = blockIdx.y * BM;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const int stem = STEMSTACK ? 0 : blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const int CPW = STEMSTACK ? p.CP2 : p.CP;
+    const float* wp = (STEMSTACK ? p.wpack2 : p.wpack + stem * p.wpack_stem) + m0;
+
+    float4 pin[NLD];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + i * 256, NF4 - 1);
+            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+            const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
+            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NF4) {
+                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+                float* d = s_in + c * CHS + il * INS + r * ROWS + 2 * j;
+                *reinterpret_cast<float2*>(d) = make_float2(pin[i].x, pin[i].z);            // even columns -> plane 0
+                *reinterpret_cast<float2*>(d + PWH) = make_float2(pin[i].y, pin[i].w);      // odd columns  -> plane 1
+            }
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int oy = sy * SH + l31 / SW, ox = sx * SW + l31 % SW;
+        boff[nr] = half * CHS + il * INS + 2 * oy * ROWS + ox;
+    }
+    const int aoff = half * 25 * BM + wm * MR * 32 + l31;
+
+    const int nchunks = p.Cin / KC;
+    srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
+    load_patch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        store_patch();
+        __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
+        const float* sw = s_w + (ch & 1) * WSLAB;
+        if (ch + 1 < nchunks) {
+            srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch((ch + 1) * KC);
+        }
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                const int ky = tap / 5, kx = tap % 5;
+                float a[MR], b[NR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[mr] = sw[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) b[nr] = s_in[boff[nr] + 2 * cp * CHS + ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // everyone is done with s_in and slab (ch&1)
+    }
+
+    const bool hasBn = p.bnScale != nullptr;
+    const size_t ohw = (size_t)Ho * Wo;
+    const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        float bi[16], sc[16], sf[16];
+        size_t ob[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1);
+            const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
+            const size_t ci = st * p.coeff_stem + co;
+            bi[r] = p.bias[ci];
+            sc[r] = hasBn ? p.bnScale[ci] : 0.0f;
+            sf[r] = hasBn ? p.bnShift[ci] : 0.0f;
+            ob[r] = st * p.out_stem + (size_t)co * ohw;
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int s = wn * NR + nr;
+            const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+            const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+            const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
+            const size_t pbase = (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pix_ok && m < mlimit) {
+                    const float v = acc[mr][nr][r] + bi[r];
+                    p.outRaw[ob[r] + pbase] = v;
+                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], p.act, p.variant);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- decoder v2
+// CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK>
+__global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
+    static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
+    static_assert(!CLASSSTACK || (BM == 32 && MR == 1), "class-stacked tiles are one 32-row M tile");
+    constexpr int PH = TH + 2, RW4 = (TW + 8) / 4;
+    constexpr int ROWS = TW + 8, INS = PH * ROWS, CHS = NI * INS;
+    constexpr int NF4 = KC * NI * PH * RW4, NLD = (NF4 + 255) / 256;
+    constexpr int NTAP = CLASSSTACK ? 15 : 25, NCLS = CLASSSTACK ? 2 : 4;
+    constexpr int WROWS = KC * NTAP, WSLAB = (WROWS * BM + 255) / 256 * 256;
+
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
+    float* s_in = s_mem;
+    float* s_w = s_mem + KC * CHS;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int tilesX = (p.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
+    const int m0 = blockIdx.y * BM;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const int CPW = CLASSSTACK ? 32 : p.CP;
+    const float* wp = (CLASSSTACK ? p.wpack2 + stem * p.wpack2_stem : p.wpack + stem * p.wpack_stem) + m0;
+
+    float4 pin[NLD];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + i * 256, NF4 - 1);
+            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
+            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NF4) {
+                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+                *reinterpret_cast<float4*>(s_in + c * CHS + il * INS + r * ROWS + 4 * j) = pin[i];
+            }
+        }
+    };
+
+    f32x16 acc[NCLS][MR][NR];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wn * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int a = sy * SH + l31 / SW, b = sx * SW + l31 % SW;
+        boff[nr] = half * CHS + il * INS + a * ROWS + b + 3;          // + (1+dy)*ROWS + (1+dx) gives column b+dx+4
+    }
+    const int aoff = half * NTAP * BM + wm * MR * 32 + l31;
+
+    const int nchunks = p.Cin / KC;
+    srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
+    load_patch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        store_patch();
+        __syncthreads();
+        const float* sw = s_w + (ch & 1) * WSLAB;
+        if (ch + 1 < nchunks) {
+            srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * NTAP * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch((ch + 1) * KC);
+        }
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+            float b[9][NR];
+#pragma unroll
+            for (int sh = 0; sh < 9; ++sh)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) b[sh][nr] = s_in[boff[nr] + 2 * cp * CHS + (sh / 3) * ROWS + (sh % 3)];
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                int cls, sh;
+                if (CLASSSTACK) {
+                    const int ky = t / 3, dxi = t % 3, py = (ky + 1) & 1, dy = (py + 1 - ky) / 2;
+                    cls = py; sh = (dy + 1) * 3 + dxi;
+                } else {
+                    const int ky = t / 5, kx = t % 5, py = (ky + 1) & 1, px = (kx + 1) & 1;
+                    const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+                    cls = py * 2 + px; sh = (dy + 1) * 3 + (dx + 1);
+                }
+                float a[MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[mr] = sw[aoff + (2 * cp * NTAP + t) * BM + mr * 32];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[cls][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[sh][nr], acc[cls][mr][nr], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float* bias = p.bias + stem * p.coeff_stem;
+    const float* scale = p.bnScale + stem * p.coeff_stem;
+    const float* shift = p.bnShift + stem * p.coeff_stem;
+    const int Ho = p.H << 1, Wo = p.W << 1;
+    const size_t ohw = (size_t)Ho * Wo;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        float bi[16], sc[16], sf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (CLASSSTACK) m &= 15;                                   // rows = px*16 + co
+            m = min(m, p.Cout - 1);
+            bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int s = wn * NR + nr;
+            const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+            const int a = ty0 + sy * SH + l31 / SW, b = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+            const bool pix_ok = tile < p.ntiles && a < p.H && b < p.W;
+            const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)(2 * a) * Wo + 2 * b : 0);
+            if (CLASSSTACK) {
+                // registers r (rows 0..15 -> px = 0) and r+8 (rows 16..31 -> px = 1) hold the same output channel
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && co < p.Cout) {
+#pragma unroll
+                        for (int py = 0; py < 2; ++py) {
+                            float2 v;
+                            v.x = srt_dec_epilogue(acc[py][0][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                            v.y = srt_dec_epilogue(acc[py][0][nr][r + 8], bi[r], sc[r], sf[r], p.act, p.variant);
+                            *reinterpret_cast<float2*>(p.outAct + obase + (size_t)co * ohw + (size_t)py * Wo) = v;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && m < p.Cout) {
+#pragma unroll
+                        for (int py = 0; py < 2; ++py) {
+                            float2 v;
+                            v.x = srt_dec_epilogue(acc[(py * 2 + 0) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                            v.y = srt_dec_epilogue(acc[(py * 2 + 1) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                            *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
+static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int mtot = STK ? p.stack * p.Cout : p.Cout;
+    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH), (mtot + BM - 1) / BM, (STK ? 1 : p.nstems) * ((p.ntiles + NI - 1) / NI));
+    hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
+static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), STK ? 1 : (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
+    hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
+{
+    if (p.W % 4) return 1;
+    const int Wo = p.W / 2;
+    if (p.Cin == 2) {                                                                    // down1, stem-stacked M
+        if (!p.wpack2 || p.stack < 1) return 1;
+        if (p.stack * p.Cout > 32) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
+        return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+    }
+    if (p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);       // down2
+    if (Wo >= 64) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);            // down3 / down4 class
+    if (Wo >= 32) return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 4, false>(p, s);            // down5 class
+    return launch_enc2_cfg<64, 2, 16, 1, 2, 4, 4, false>(p, s);                          // down6 class
+}
+
+int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
+{
+    if (p.W % 4 || p.Cout < 16) return 1;
+    if (p.Cout == 16) return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s) : 1;   // up5, class-stacked M
+    if (p.Cout <= 32) return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);        // up4
+    if (p.W >= 32) return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);           // up2 / up3
+    return launch_dec2_cfg<64, 2, 16, 1, 2, 2, 4, false>(p, s);                          // up1
+}
