@@ -148,10 +148,16 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-#define ISTFT_FPB 2
-
-// per frame: read the spectrum row once, then for every stem: mask multiply -> inverse FFT -> post-window -> frame buffer
-__global__ void __launch_bounds__(256) srt_istft_kernel(const SrtIstftParams p)
+// Inverse STFT with the overlap-add fused in (no frame scratch, no second pass, no atomics).
+// With the radix-16 FFT's output distribution thread w holds samples w + 256*k2 of a frame, i.e. for each of the four
+// 1024-sample quarters the SAME four in-hop offsets q_j = w + 256 j.  Overlap-add across frames is therefore
+// thread-local: a workgroup walks a run of consecutive frames and keeps, per stem, a rolling window of four partial
+// output segments in registers; segment s is complete once frame s has been added (frames s-3..s, added in that
+// order = the reference's accumulation order, stftFix.c:570-575) and is written out exactly once.  A workgroup that
+// owns segments [s0, s1) recomputes the three frames before s0 as warm-up ((G+3)/G extra work).
+// The stems of a group are processed back to back for one frame, so the spectrum row is served from L1/L2 after the first.
+template <int NS>
+__global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G, int stem0)
 {
     __shared__ float2 s_tw[4096];
     __shared__ float2 s_x[FFT_SMEM_F2];
@@ -159,85 +165,96 @@ __global__ void __launch_bounds__(256) srt_istft_kernel(const SrtIstftParams p)
     for (int i = tid; i < 4096; i += 256) s_tw[i] = p.tab.twiddle[i];
     __syncthreads();
     const size_t tf = (size_t)p.T * p.F;
+    const int nseg = p.frames + 3;
+    const int s0 = blockIdx.x * G, s1 = min(s0 + G, nseg);
+    const int nst = min(NS, p.nstems - stem0);
 
-    for (int fi = 0; fi < ISTFT_FPB; ++fi) {
-        const int f = blockIdx.x * ISTFT_FPB + fi;
-        if (f >= p.frames) break;
-        const int tile = f / p.T, t = f % p.T;
-        const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
-        const float2* specR = specL + p.spec_ch_stride;
-        float2 sl[9], sr[9];
+    float accL[NS][4][4], accR[NS][4][4];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int k = tid + 256 * j;
-            if (k <= 2048) { sl[j] = specL[k]; sr[j] = specR[k]; }
-        }
-        for (int st = 0; st < p.nstems; ++st) {
-            const float* mL = p.masks ? p.masks + ((size_t)(st * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
-            const float* mR = mL ? mL + tf : nullptr;
+    for (int st = 0; st < NS; ++st)
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int k = tid + 256 * j;
-                if (k <= 2048) {
-                    float gl = p.oob[st], gr = p.oob[st];                   // bins >= F: "unaffectedWeight" (main.c:486-493)
-                    if (k < p.F) { gl = mL ? mL[k] : 1.0f; gr = mR ? mR[k] : 1.0f; }
-                    const float reL = sl[j].x * gl, imL = sl[j].y * gl, reR = sr[j].x * gr, imR = sr[j].y * gr;
-                    // G = F'_L + i F'_R with F' = re - i im, Hermitian-extended; stored swapped (im,re) for the inverse-by-forward trick
-                    if (k == 0) s_x[0] = f2(reR, reL);                     // a[0] = re[0]            (stftFix.c:556-557)
-                    else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);   // rev[2048]: re - im wins (stftFix.c:563-566)
-                    else {
-                        s_x[k] = f2(reR - imL, reL + imR);
-                        s_x[4096 - k] = f2(reR + imL, reL - imR);
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { accL[st][h][j] = 0.0f; accR[st][h][j] = 0.0f; }
+
+    for (int f = s0 - 3; f < s1; ++f) {
+        const bool live = f >= 0 && f < p.frames;                    // workgroup-uniform
+        if (live) {
+            const int tile = f / p.T, t = f % p.T;
+            const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
+            const float2* specR = specL + p.spec_ch_stride;
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st < nst) {
+                    const int sg = stem0 + st;
+                    const float* mL = p.masks ? p.masks + ((size_t)(sg * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
+                    const float* mR = mL ? mL + tf : nullptr;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int k = tid + 256 * j;
+                        if (k <= 2048) {
+                            const float2 sl = specL[k], sr = specR[k];       // re-read per stem: L1/L2 hit, keeps 36 VGPRs free
+                            float gl = p.oob[sg], gr = p.oob[sg];            // bins >= F: "unaffectedWeight" (main.c:486-493)
+                            if (k < p.F) { gl = mL ? mL[k] : 1.0f; gr = mR ? mR[k] : 1.0f; }
+                            const float reL = sl.x * gl, imL = sl.y * gl, reR = sr.x * gr, imR = sr.y * gr;
+                            // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; stored swapped (im,re): inverse-by-forward trick
+                            if (k == 0) s_x[0] = f2(reR, reL);                                // a[0] = re[0]           (stftFix.c:556-557)
+                            else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);        // rev[2048]: re - im wins (stftFix.c:563-566)
+                            else {
+                                s_x[k] = f2(reR - imL, reL + imR);
+                                s_x[4096 - k] = f2(reR + imL, reL - imR);
+                            }
+                        }
                     }
+                    __syncthreads();
+                    float2 v[16];
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
+                    __syncthreads();
+                    fft4096(v, s_x, s_tw, tid);
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const float w = p.tab.postWin[tid + 256 * k2];
+                        const float2 y = v[FFT16_AT(k2)];                                     // swapped back: L = y.y, R = y.x
+                        accL[st][k2 >> 2][k2 & 3] += y.y * w;
+                        accR[st][k2 >> 2][k2 & 3] += y.x * w;
+                    }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
-            float2 v[16];
+        }
+        // segment f is complete: emit it, then slide the window
+        const bool emit = f >= s0;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
-            __syncthreads();
-            fft4096(v, s_x, s_tw, tid);
-            float* oL = p.frames_out + ((size_t)(st * 2 + 0) * p.frames + f) * SRT_FFT;
-            float* oR = p.frames_out + ((size_t)(st * 2 + 1) * p.frames + f) * SRT_FFT;
+        for (int st = 0; st < NS; ++st) {
+            if (st < nst) {
+                if (emit) {
+                    float* oL = p.out + (size_t)((stem0 + st) * 2 + 0) * p.out_len + (size_t)f * SRT_HOP;
+                    float* oR = p.out + (size_t)((stem0 + st) * 2 + 1) * p.out_len + (size_t)f * SRT_HOP;
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) {
-                const int q = tid + 256 * k2;
-                const float w = p.tab.postWin[q];
-                const float2 y = v[FFT16_AT(k2)];                          // swapped back: L = y.y, R = y.x
-                oL[q] = y.y * w;
-                oR[q] = y.x * w;
+                    for (int j = 0; j < 4; ++j) { oL[tid + 256 * j] = accL[st][0][j]; oR[tid + 256 * j] = accR[st][0][j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    accL[st][0][j] = accL[st][1][j]; accL[st][1][j] = accL[st][2][j]; accL[st][2][j] = accL[st][3][j]; accL[st][3][j] = 0.0f;
+                    accR[st][0][j] = accR[st][1][j]; accR[st][1][j] = accR[st][2][j]; accR[st][2][j] = accR[st][3][j]; accR[st][3][j] = 0.0f;
+                }
             }
-            __syncthreads();
         }
-    }
-}
-
-// out[i] = sum of the (up to) four frames covering sample i, added in frame order (stftFix.c:570-575)
-__global__ void srt_ola_kernel(const SrtIstftParams p)
-{
-    const size_t total = (size_t)p.nstems * 2 * p.out_len;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = e % p.out_len, sc = e / p.out_len;            // sc = stem*2 + ch
-        const int seg = (int)(i / SRT_HOP), q = (int)(i % SRT_HOP);
-        const float* fr = p.frames_out + sc * (size_t)p.frames * SRT_FFT;
-        float acc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = seg - 3 + j;
-            if (f >= 0 && f < p.frames) acc += fr[(size_t)f * SRT_FFT + q + (3 - j) * SRT_HOP];
-        }
-        p.out[sc * p.out_len + i] = acc;
     }
 }
 
 int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
 {
     if (p.frames <= 0) return 0;
-    hipLaunchKernelGGL(srt_istft_kernel, dim3((p.frames + ISTFT_FPB - 1) / ISTFT_FPB), dim3(256), 0, s, p);
-    if (hipGetLastError() != hipSuccess) return -1;
-    const size_t total = (size_t)p.nstems * 2 * p.out_len;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(srt_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int nseg = p.frames + 3;
+    int G = (nseg + 511) / 512;                       // ~2 workgroups per CU when the stream is long enough
+    if (G < 13) G = 13;                               // keep the 3-frame warm-up below ~25 %
+    const int blocks = (nseg + G - 1) / G;
+    // two stems per workgroup: 64 accumulator registers + the FFT fit in 256 VGPRs at 2 workgroups per CU (four stems spill)
+    for (int st0 = 0; st0 < p.nstems; st0 += 2) {
+        hipLaunchKernelGGL((srt_istft_ola_kernel<2>), dim3(blocks), dim3(256), 0, s, p, G, st0);
+        if (hipGetLastError() != hipSuccess) return -1;
+    }
+    return 0;
 }

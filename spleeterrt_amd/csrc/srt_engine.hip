@@ -292,18 +292,6 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
 
 static SrtDspTables tables_of(const srt_engine* e) { SrtDspTables t; t.preWin = e->preWin; t.postWin = e->postWin; t.twiddle = e->twiddle; return t; }
 
-// grow-only scratch for the windowed time frames written by the inverse FFT kernel
-static int ensure_frames(srt_engine* e, size_t rows)
-{
-    if (rows <= e->frames_rows) return 0;
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->frames) hipFree(e->frames);
-    e->frames = nullptr; e->frames_rows = 0;
-    HIPCHK(hipMalloc((void**)&e->frames, (size_t)e->cfg.n_stems * 2 * rows * SRT_FFT * sizeof(float)));
-    e->frames_rows = rows;
-    return 0;
-}
-
 int srtStftEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_spec, float* d_mag)
 {
     if (!e || !d_L || !d_R || !d_spec) return fail(-1, "srtStft: null argument");
@@ -339,14 +327,12 @@ int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_mas
     if (rows < 1) return fail(-1, "srtIstft: no rows");
     const int T = e->cfg.T;
     if (d_masks && (rows + T - 1) / T > (size_t)e->cfg.max_tiles) return fail(-1, "srtIstft: rows exceed max_tiles * T");
-    int rc = ensure_frames(e, rows);
-    if (rc) return rc;
     SrtIstftParams p; memset(&p, 0, sizeof p);
     p.spec = (const float2*)d_spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
     p.frames = (int)rows; p.masks = d_masks; p.nstems = e->cfg.n_stems; p.ntiles = (int)((rows + T - 1) / T);
     p.T = T; p.F = e->cfg.F;
     for (int s = 0; s < SRT_MAX_STEMS; ++s) p.oob[s] = e->cfg.oob_weight[s];
-    p.frames_out = e->frames; p.out = d_out; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
+    p.frames_out = nullptr; p.out = d_out; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
     TimerScope ts(e, "istft");
     if (srt_launch_istft(p, e->stream)) return fail(-2, "istft launch failed");
     return 0;

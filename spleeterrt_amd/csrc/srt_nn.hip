@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // GATHERS its taps from LDS (no scatter, no atomics) with bias -> act -> BN fused.  B operands come straight from
 // global memory (every element feeds exactly one MFMA, so LDS staging would buy nothing).
 template <int TH, int TW, int CIN>
-__global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
+__global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
 {
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
     __shared__ float s_col[25 * NPAD];
@@ -499,27 +499,35 @@ __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
         const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
         a[cp] = l31 < 25 ? v : 0.0f;
     }
-    for (int sub = wave; sub < NSUB; sub += 4) {
+    // software pipeline: the B fragments of sub-tile s+4 are in flight while sub-tile s runs its 16 MFMAs
+    auto load_b = [&](int sub, float (&b)[CIN / 2]) {
         const int pix = sub * 32 + l31, pr = pix / PW, pc = pix % PW;
         const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
-        const bool ok = pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool ok = sub < NSUB && pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         const size_t off = ok ? (size_t)gy * p.W + gx : 0;
-        float b[CIN / 2];
 #pragma unroll
         for (int cp = 0; cp < CIN / 2; ++cp) {
             const float v = srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
             b[cp] = ok ? v : 0.0f;
         }
+    };
+    float bcur[CIN / 2], bnext[CIN / 2];
+    load_b(wave, bcur);
+    for (int sub = wave; sub < NSUB; sub += 4) {
+        load_b(sub + 4, bnext);
+        const int pix = sub * 32 + l31;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+        for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], bcur[cp], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (tap < 25) s_col[tap * NPAD + pix] = acc[r];
         }
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) bcur[cp] = bnext[cp];
     }
     __syncthreads();
     const float bi = p.bias[stem * p.coeff_stem], sc = p.bnScale[stem * p.coeff_stem], sf = p.bnShift[stem * p.coeff_stem];
@@ -592,7 +600,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
-        constexpr int TH = 16, TW = 32;
+        constexpr int TH = 8, TW = 32;
         dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), 1, p.nstems * p.ntiles);
         hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), grid, dim3(256), 0, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
