@@ -54,14 +54,25 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
     for (int k0 = 0; k0 < 4; ++k0) dft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
 
+// Per-thread twiddles are frame independent, so each workgroup re-lays the (double-precision generated) table once
+// into the order its threads read it: twA[k0-1][tid] = W^(tid*k0), twB[k1-1][lo] = W^(16*lo*k1).  All twiddle reads are
+// then consecutive or broadcast (conflict-free), instead of stride-k gathers into a 4096-entry table.
+#define FFT_TW_F2 (15 * 256 + 15 * 16)
+__device__ __forceinline__ void fft_load_twiddles(float2* tw, const float2* __restrict__ table, int tid)
+{
+#pragma unroll
+    for (int k0 = 1; k0 < 16; ++k0) tw[(k0 - 1) * 256 + tid] = table[(tid * k0) & 4095];
+    if (tid < 240) tw[15 * 256 + tid] = table[(16 * (tid & 15) * (tid / 16 + 1)) & 4095];
+}
+
 // 4096-point forward FFT.  In: v[n2] = x[tid + 256*n2].  Out: v[FFT16_AT(k2)] = X[tid + 256*k2].
-// s: FFT_SMEM_F2 float2 of LDS scratch, tw: 4096-entry table exp(-2 pi i j / 4096) in LDS.
+// s: FFT_SMEM_F2 float2 of LDS scratch, tw: the re-laid twiddles (fft_load_twiddles).
 // The caller must __syncthreads() before reusing s after return.
 __device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2* tw, int tid)
 {
     fft16(v);                                            // over n2 -> k0
 #pragma unroll
-    for (int k0 = 1; k0 < 16; ++k0) v[FFT16_AT(k0)] = cmul(v[FFT16_AT(k0)], tw[(tid * k0) & 4095]);
+    for (int k0 = 1; k0 < 16; ++k0) v[FFT16_AT(k0)] = cmul(v[FFT16_AT(k0)], tw[(k0 - 1) * 256 + tid]);
 #pragma unroll
     for (int k0 = 0; k0 < 16; ++k0) s[k0 * FFT_EX1_LD + tid] = v[FFT16_AT(k0)];
     __syncthreads();
@@ -70,7 +81,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = s[hi * FFT_EX1_LD + n1 * 16 + lo];
     fft16(v);                                            // over n1 -> k1
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) v[FFT16_AT(k1)] = cmul(v[FFT16_AT(k1)], tw[(16 * lo * k1) & 4095]);
+    for (int k1 = 1; k1 < 16; ++k1) v[FFT16_AT(k1)] = cmul(v[FFT16_AT(k1)], tw[15 * 256 + (k1 - 1) * 16 + lo]);
     __syncthreads();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) s[lo * FFT_EX2_LD + k1 * 16 + hi] = v[FFT16_AT(k1)];
@@ -80,14 +91,14 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2
     fft16(v);                                            // over n0 -> k2
 }
 
-#define STFT_FPB 4      // frames per workgroup (amortises the twiddle-table load; consecutive frames share 75% of input)
+#define STFT_FPB 8      // frames per workgroup (amortises the twiddle-table load; consecutive frames share 75% of input)
 
 __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
 {
-    __shared__ float2 s_tw[4096];
+    __shared__ float2 s_tw[FFT_TW_F2];
     __shared__ float2 s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 4096; i += 256) s_tw[i] = p.tab.twiddle[i];
+    fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
 
     for (int fi = 0; fi < STFT_FPB; ++fi) {
@@ -159,10 +170,10 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
 template <int NS>
 __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G, int stem0)
 {
-    __shared__ float2 s_tw[4096];
+    __shared__ float2 s_tw[FFT_TW_F2];
     __shared__ float2 s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 4096; i += 256) s_tw[i] = p.tab.twiddle[i];
+    fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
     const size_t tf = (size_t)p.T * p.F;
     const int nseg = p.frames + 3;
