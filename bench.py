@@ -37,6 +37,16 @@ for i, (ci, co) in enumerate(_dec):
     LAYER_FLOP["up%d" % (i + 1)] = 2 * co * ci * 25 * (T >> (6 - i)) * (F >> (6 - i))
 LAYER_FLOP["up7"] = 2 * 2 * 16 * T * F
 assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
+# kernel symbol (as rocprofv3 prints it) that runs each layer at T=256, F=1024; layers sharing a symbol have equal FLOPs
+LAYER_SYMBOL = {
+    "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 4, false>",
+    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false>", "down4": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false>",
+    "down5": "srt_enc_mfma2<64, 2, 32, 1, 8, 1, 4, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false>",
+    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false>",
+    "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false>",
+    "up5": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, true>", "up6": "srt_up6_kernel<8, 32, 32>", "up7": "srt_head_kernel",
+}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc.json")     # written by scripts/summarize_profiles.py from separate --pmc passes
 
 
 def synth_weights(stem, device):
@@ -178,8 +188,29 @@ def main():
         inst = STEMS * a.tiles
         nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP)
         nn_flop = FLOP_PER_PIXEL * T * F * inst
-        dom = max((k for k in avg if k in LAYER_FLOP), key=lambda k: avg[k])
-        dom_tflops = LAYER_FLOP[dom] * inst / (avg[dom] * 1e-3) / 1e12
+        # dominant kernel = the kernel SYMBOL with the largest share of the step (what tops rocprofv3 --stats);
+        # achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the engine's stream)
+        sym_ms, sym_flop, sym_n = {}, {}, {}
+        for k in avg:
+            if k in LAYER_FLOP and (a.impl == "mfma" and a.tiles == TILES):
+                sy = LAYER_SYMBOL[k]
+            else:
+                sy = k
+            if k in LAYER_FLOP:
+                sym_ms[sy] = sym_ms.get(sy, 0.0) + avg[k]
+                sym_flop[sy] = sym_flop.get(sy, 0.0) + LAYER_FLOP[k] * inst
+                sym_n[sy] = sym_n.get(sy, 0) + 1
+        dom = max(sym_ms, key=lambda k: sym_ms[k])
+        dom_ms = sym_ms[dom] / sym_n[dom]
+        dom_flop = sym_flop[dom] / sym_n[dom]
+        dom_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
+        traffic = None
+        try:
+            pm = json.load(open(PMC_SUMMARY)).get(dom)
+            if pm and a.tiles == TILES:
+                traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "x_realtime (4-stem separation, 44.1 kHz stereo, PCM->stems resident in HBM); frames_per_s alongside",
             "value": fps * HOP / FS, "unit": "x real-time", "frames_per_s": fps,
@@ -190,8 +221,9 @@ def main():
                        "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
                        "impl": a.impl},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "flop_per_launch": LAYER_FLOP[dom] * inst, "avg_ms_per_launch": avg[dom]},
+                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc.json)",
+                         "flop_per_launch": dom_flop, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],
+                         "share_of_step": sym_ms[dom] / (dt / a.steps * 1e3)},
             "nn_stack": {"achieved_tflops": nn_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "ms": nn_ms, "flop": nn_flop},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
