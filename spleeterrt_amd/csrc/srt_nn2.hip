@@ -424,7 +424,7 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
-    if (p.Cout == 16) return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s) : 1;   // up5, class-stacked M (KC = 8 measured 6 % slower)
+    if (p.Cout == 16) return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s) : 1;   // up5, class-stacked M (KC = 8: 6 % slower; 8x64 tile: 14 % slower)
     if (p.Cout <= 32) return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);        // up4 (KC = 8 measured 5 % slower)
     if (p.W >= 32) return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);           // up2 / up3
     return launch_dec2_cfg<64, 2, 16, 1, 2, 2, 4, false>(p, s);                          // up1
