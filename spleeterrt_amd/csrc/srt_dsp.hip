@@ -269,3 +269,101 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------- streaming hop
+// Inverse of the DELAYED frame for one stem (blockIdx.x = stem): masked spectrum -> time frame -> synthesis window on the
+// last 2048 samples -> 50 % overlap-add with the kept half -> interleaved-by-8 output segment (Spleeter4Stems.c:64-101,272-320).
+__global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStreamHop p)
+{
+    __shared__ float2 s_tw[FFT_TW_F2];
+    __shared__ float2 s_x[FFT_SMEM_F2];
+    const int tid = threadIdx.x, st = blockIdx.x;
+    fft_load_twiddles(s_tw, p.twiddle, tid);
+    const float2* specL = p.specRow;
+    const float2* specR = p.specRow + p.specChStride;
+    const float* mL = p.maskRow + st * p.maskStemStride;
+    const float* mR = mL + p.maskChStride;
+    const float oob = st == 1 ? 0.0f : 0.25f;                      // Spleeter4Stems.c:73,281
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int k = tid + 256 * j;
+        if (k <= 2048) {
+            const float2 sl = specL[k], sr = specR[k];
+            float gl = oob, gr = oob;
+            if (k < p.F) { gl = mL[k]; gr = mR[k]; }
+            const float reL = sl.x * gl, imL = sl.y * gl, reR = sr.x * gr, imR = sr.y * gr;
+            if (k == 0) s_x[0] = f2(reR, reL);
+            else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);
+            else {
+                s_x[k] = f2(reR - imL, reL + imR);
+                s_x[4096 - k] = f2(reR + imL, reL - imR);
+            }
+        }
+    }
+    __syncthreads();
+    float2 v[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
+    __syncthreads();
+    fft4096(v, s_x, s_tw, tid);
+    float* ovL = p.overlap + (size_t)(2 * st) * 1024;
+    float* ovR = ovL + 1024;
+    // thread holds samples tid + 256*k2; only the last 2048 are synthesised.  k2 = 8..11 -> output, 12..15 -> kept half.
+#pragma unroll
+    for (int k2 = 8; k2 < 12; ++k2) {
+        const int i = tid + 256 * (k2 - 8);                                   // 0..1023
+        const float w0 = p.synthesisWnd[i], w1 = p.synthesisWnd[i + 1024];
+        const float2 y0 = v[FFT16_AT(k2)], y1 = v[FFT16_AT(k2 + 4)];
+        p.out[(size_t)i * 8 + 2 * st + 0] = ovL[i] + y0.y * w0;              // mOverlapStage2dash + timeDomainOut (:313-315)
+        p.out[(size_t)i * 8 + 2 * st + 1] = ovR[i] + y0.x * w0;
+        ovL[i] = y1.y * w1;                                                   // :317-318
+        ovR[i] = y1.x * w1;
+    }
+}
+
+// Forward transform of the CURRENT 4096 ring samples with the asymmetric analysis window; spectrum + magnitude rows
+// of the collecting batch (Spleeter4Stems.c:261-267,322-349).
+__global__ void __launch_bounds__(256) srt_stream_forward_kernel(const SrtStreamHop p)
+{
+    __shared__ float2 s_tw[FFT_TW_F2];
+    __shared__ float2 s_x[FFT_SMEM_F2];
+    const int tid = threadIdx.x;
+    fft_load_twiddles(s_tw, p.twiddle, tid);
+    __syncthreads();
+    float2 v[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        const int n = tid + 256 * n2, k = (n + p.inPos) & 4095;
+        const float w = p.analysisWnd[n];
+        v[n2] = f2(p.ring[k] * w, p.ring[4096 + k] * w);
+    }
+    fft4096(v, s_x, s_tw, tid);
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) s_x[tid + 256 * k2] = v[FFT16_AT(k2)];
+    __syncthreads();
+    float2* specL = p.specRow;
+    float2* specR = p.specRow + p.specChStride;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int k = tid + 256 * j;
+        if (k <= 2048) {
+            const float2 zk = s_x[k], zm = s_x[(4096 - k) & 4095];
+            const float2 sl = f2(zk.x + zm.x, zm.y - zk.y);
+            const float2 sr = f2(zk.y + zm.y, zk.x - zm.x);
+            specL[k] = sl; specR[k] = sr;
+            if (k < p.F) {
+                p.magRow[k] = hypotf(sl.x, sl.y) * 4096.0f;
+                p.magRow[p.magChStride + k] = hypotf(sr.x, sr.y) * 4096.0f;
+            }
+        }
+    }
+}
+
+int srt_launch_stream_hop(const SrtStreamHop& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_stream_inverse_kernel, dim3(4), dim3(256), 0, s, p);     // reads the delayed row ...
+    if (hipGetLastError() != hipSuccess) return -1;
+    hipLaunchKernelGGL(srt_stream_forward_kernel, dim3(1), dim3(256), 0, s, p);     // ... before the current frame overwrites it
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -89,3 +89,20 @@ struct SrtIstftParams {
 };
 int srt_launch_stft(const SrtStftParams& p, hipStream_t s);
 int srt_launch_istft(const SrtIstftParams& p, hipStream_t s);
+
+// streaming (srt_dsp.hip kernels, srt_stream.hip host logic): one hop = 1 forward + 4 masked inverse FFTs + 50 % OLA
+struct SrtStreamHop {
+    const float* ring;        // [2][4096] device copy of the input ring buffer
+    int inPos;                // ring read origin (Spleeter4Stems.c:262)
+    float2* specRow;          // [2 ch] rows of the spectrum buffer for this cursor: L at specRow, R at specRow + specChStride
+    size_t specChStride;
+    float* magRow;            // [2 ch] magnitude rows: L at magRow, R at magRow + magChStride
+    size_t magChStride;
+    const float* maskRow;     // stem s, channel c at maskRow + s*maskStemStride + c*maskChStride
+    size_t maskStemStride, maskChStride;
+    int F;
+    float* overlap;           // [8][1024]
+    float* out;               // [1024][8] interleaved segment
+    const float* analysisWnd; const float* synthesisWnd; const float2* twiddle;
+};
+int srt_launch_stream_hop(const SrtStreamHop& p, hipStream_t s);

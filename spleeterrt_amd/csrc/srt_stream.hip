@@ -1,0 +1,175 @@
+// srt_stream.hip — the reference's real-time streaming surface (include/Spleeter4Stems.h) on the GPU engine.
+//
+// Host side keeps exactly the reference's bookkeeping (input ring, "samples needed" counter, two queued output
+// segments interleaved by 8: VST/Source/Spleeter4Stems.c:512-582); every completed hop launches
+//   srt_stream_inverse_kernel  x4 stems : delayed spectrum row x mask -> inverse FFT -> synthesis window -> 50 % OLA
+//   srt_stream_forward_kernel           : asymmetric-window FFT of the current 4096 samples -> spectrum + magnitude row
+// on the hop stream and copies the 1024 x 8 segment back.  Every timeStep hops the four U-Nets are started on the
+// engine's own stream (the reference's task_type2 threads, Spleeter4Stems.c:135,351-371) and joined one batch later.
+#include "srt_internal.h"
+#include "../../include/spleeterrt_amd.h"
+#include "../../include/Spleeter4Stems.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define HIPDIE(x, where) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "libspleeterrt_amd: %s: %s\n", where, hipGetErrorString(_e)); abort(); } } while (0)
+
+namespace {
+struct Stream {
+    srt_engine* eng;
+    hipStream_t hop, nn;
+    hipEvent_t evMag, evNN;
+    int F, T, cursor, ptr;
+    bool nnRunning;
+    float* d_ring; float2* d_spec; float* d_mag; float* d_tmp; float* d_masks; float* d_overlap; float* d_out;
+    float *d_awin, *d_swin; float2* d_tw;
+    size_t hw;
+    // host state, mirrors Spleeter4Stems.h:35-47
+    float ring[2][FFTSIZE];
+    unsigned inPos, needed;
+    float* outq[2]; float* pinned;            // two queued segments of OUTPUTSEG*8 floats (pinned for the D2H copy)
+    int outCount, outReadOff;
+};
+
+void asymmetric_window(std::vector<float>& an, std::vector<float>& sy)      // Spleeter4Stems.c:383-401 with k=4096, m=1024, p=1
+{
+    const int k = FFTSIZE, m = OVPSIZE;
+    const double PI = 3.141592653589793;
+    an.assign(k, 0.f); sy.assign(k, 0.f);
+    int n = ((k - m) << 1) + 2;
+    for (int i = 0; i < k - m; ++i) an[i] = (float)pow(0.5 * (1.0 - cos(2.0 * PI * (i + 1.0) / (double)n)), 1.0);
+    n = (m << 1) + 2;
+    for (int i = k - m; i < k; ++i) an[i] = (float)pow(sqrt(0.5 * (1.0 - cos(2.0 * PI * ((m + i - (k - m)) + 1.0) / (double)n))), 1.0);
+    n = m << 1;
+    for (int i = k - (m << 1); i < k; ++i) sy[i] = (float)(0.5 * (1.0 - cos(2.0 * PI * (double)(i - (k - (m << 1))) / (double)n))) / an[i];
+    for (int i = 0; i < k - SAMPLESHIFT; ++i) sy[i] = sy[i + SAMPLESHIFT];   // pre-shift
+    for (int i = 0; i < k; ++i) an[i] *= (1.0 / FFTSIZE) * 0.5f;             // Spleeter4Stems.c:414-416 (double product, float store)
+}
+
+void process_hop(Stream* s)                                                  // LLPAMSProcessNPR, Spleeter4Stems.c:257-381
+{
+    const size_t rowF2 = SRT_SPEC_LD, bufF2 = 2 * (size_t)s->T * rowF2;
+    HIPDIE(hipMemcpyAsync(s->d_ring, s->ring, sizeof s->ring, hipMemcpyHostToDevice, s->hop), "stream hop");
+    SrtStreamHop p; memset(&p, 0, sizeof p);
+    p.ring = s->d_ring; p.inPos = (int)s->inPos;
+    p.specRow = s->d_spec + s->ptr * bufF2 + (size_t)s->cursor * rowF2; p.specChStride = (size_t)s->T * rowF2;
+    p.magRow = s->d_mag + (size_t)s->cursor * s->F; p.magChStride = s->hw;
+    p.maskRow = s->d_masks + (size_t)s->ptr * 4 * 2 * s->hw + (size_t)s->cursor * s->F; p.maskStemStride = 2 * s->hw; p.maskChStride = s->hw;
+    p.F = s->F; p.overlap = s->d_overlap; p.out = s->d_out;
+    p.analysisWnd = s->d_awin; p.synthesisWnd = s->d_swin; p.twiddle = s->d_tw;
+    if (srt_launch_stream_hop(p, s->hop)) { fprintf(stderr, "libspleeterrt_amd: stream hop launch failed\n"); abort(); }
+    if (s->outCount >= 2) { float* t = s->outq[0]; s->outq[0] = s->outq[1]; s->outq[1] = t; s->outCount = 1; s->outReadOff = 0; }   // the reference overruns its 2-slot queue here (caller passed > 1024 samples without draining); drop the oldest segment instead
+    float* dst = s->outq[s->outCount];
+    HIPDIE(hipMemcpyAsync(dst, s->d_out, OUTPUTSEG * 8 * sizeof(float), hipMemcpyDeviceToHost, s->hop), "stream hop");
+    s->outCount++;
+    s->cursor++;
+    if (s->cursor >= s->T) {
+        // join the networks started one batch ago (their masks land in buffer !ptr), flip, start on this batch's magnitudes
+        if (s->nnRunning) HIPDIE(hipStreamWaitEvent(s->hop, s->evNN, 0), "stream join");
+        s->ptr = !s->ptr;
+        HIPDIE(hipMemcpyAsync(s->d_tmp, s->d_mag, 2 * s->hw * sizeof(float), hipMemcpyDeviceToDevice, s->hop), "stream flip");   // "Prevent race condition" copy (:364-365)
+        HIPDIE(hipEventRecord(s->evMag, s->hop), "stream flip");
+        HIPDIE(hipStreamWaitEvent(s->nn, s->evMag, 0), "stream flip");
+        if (srtForward(s->eng, s->d_tmp, 1, s->d_masks + (size_t)(!s->ptr) * 4 * 2 * s->hw)) { fprintf(stderr, "libspleeterrt_amd: %s\n", srtLastError()); abort(); }
+        HIPDIE(hipEventRecord(s->evNN, s->nn), "stream flip");
+        s->nnRunning = true;
+        s->cursor = 0;
+    }
+    HIPDIE(hipStreamSynchronize(s->hop), "stream hop");                      // the segment must be in host memory before the callback returns
+    s->needed = OUTPUTSEG;
+}
+}  // namespace
+
+void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4])
+{
+    Stream* s = new Stream();
+    memset(s, 0, sizeof *s);
+    s->F = F; s->T = T; s->hw = (size_t)F * T;
+    HIPDIE(hipStreamCreate(&s->hop), "Spleeter4StemsInit");
+    HIPDIE(hipStreamCreate(&s->nn), "Spleeter4StemsInit");
+    HIPDIE(hipEventCreateWithFlags(&s->evMag, hipEventDisableTiming), "Spleeter4StemsInit");
+    HIPDIE(hipEventCreateWithFlags(&s->evNN, hipEventDisableTiming), "Spleeter4StemsInit");
+    srt_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.F = F; cfg.T = T; cfg.n_stems = 4; cfg.variant = SRT_VARIANT_VST; cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA;
+    for (int k = 0; k < 4; ++k) { cfg.stem_mode[k] = 1; cfg.oob_weight[k] = k == 1 ? 0.0f : 0.25f; }      // Spleeter4Stems.c:444-447
+    if (srtCreate(&cfg, s->nn, &s->eng)) { fprintf(stderr, "libspleeterrt_amd: Spleeter4StemsInit: %s\n", srtLastError()); abort(); }
+    for (int k = 0; k < 4; ++k)
+        if (srtSetCoeffHost(s->eng, k, coeffProvider[k])) { fprintf(stderr, "libspleeterrt_amd: Spleeter4StemsInit: %s\n", srtLastError()); abort(); }
+    const size_t specF = 2 * 2 * (size_t)T * SRT_SPEC_LD * 2;
+    HIPDIE(hipMalloc((void**)&s->d_ring, sizeof s->ring), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_spec, specF * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_mag, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_tmp, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_masks, 2 * 4 * 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_overlap, 8 * 1024 * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_out, OUTPUTSEG * 8 * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_awin, FFTSIZE * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_swin, FFTSIZE * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMalloc((void**)&s->d_tw, FFTSIZE * sizeof(float2)), "Spleeter4StemsInit");
+    HIPDIE(hipMemset(s->d_spec, 0, specF * sizeof(float)), "Spleeter4StemsInit");              // zero spectrum for the first 2T hops (:423-438)
+    HIPDIE(hipMemset(s->d_mag, 0, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
+    HIPDIE(hipMemset(s->d_overlap, 0, 8 * 1024 * sizeof(float)), "Spleeter4StemsInit");
+    std::vector<float> ones(2 * 4 * 2 * s->hw, 1.0f), an, sy, tw(2 * FFTSIZE);                 // masks start at 1.0 (:456-467)
+    HIPDIE(hipMemcpy(s->d_masks, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice), "Spleeter4StemsInit");
+    asymmetric_window(an, sy);
+    const double w0 = 6.283185307179586476925286766559 / FFTSIZE;
+    for (int i = 0; i < FFTSIZE; ++i) { tw[2 * i] = (float)cos(w0 * i); tw[2 * i + 1] = (float)(-sin(w0 * i)); }
+    HIPDIE(hipMemcpy(s->d_awin, an.data(), FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
+    HIPDIE(hipMemcpy(s->d_swin, sy.data(), FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
+    HIPDIE(hipMemcpy(s->d_tw, tw.data(), 2 * FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
+    HIPDIE(hipHostMalloc((void**)&s->pinned, 2 * OUTPUTSEG * 8 * sizeof(float), hipHostMallocDefault), "Spleeter4StemsInit");
+    s->outq[0] = s->pinned; s->outq[1] = s->pinned + OUTPUTSEG * 8;
+    s->needed = OUTPUTSEG; s->inPos = 0; s->outCount = 0; s->outReadOff = 0; s->cursor = 0; s->ptr = 0; s->nnRunning = false;
+    memset(msr, 0, sizeof *msr);
+    msr->impl = s;
+}
+
+void Spleeter4StemsFree(Spleeter4Stems* msr)
+{
+    if (!msr || !msr->impl) return;
+    Stream* s = (Stream*)msr->impl;
+    hipStreamSynchronize(s->hop); hipStreamSynchronize(s->nn);
+    srtDestroy(s->eng);
+    void* d[] = { s->d_ring, s->d_spec, s->d_mag, s->d_tmp, s->d_masks, s->d_overlap, s->d_out, s->d_awin, s->d_swin, s->d_tw };
+    for (void* q : d) hipFree(q);
+    hipHostFree(s->pinned);
+    hipEventDestroy(s->evMag); hipEventDestroy(s->evNN);
+    hipStreamDestroy(s->hop); hipStreamDestroy(s->nn);
+    delete s;
+    msr->impl = nullptr;
+}
+
+void Spleeter4StemsProcessSamples(Spleeter4Stems* msr, const float* inLeft, const float* inRight, int inSampleCount, float** components)
+{
+    Stream* s = (Stream*)msr->impl;
+    int outSampleCount = 0;
+    const int maxOut = inSampleCount;
+    while (inSampleCount > 0) {                                             // Spleeter4Stems.c:518-537
+        const int c = (int)s->needed < inSampleCount ? (int)s->needed : inSampleCount;
+        memcpy(&s->ring[0][s->inPos], inLeft, c * sizeof(float));
+        memcpy(&s->ring[1][s->inPos], inRight, c * sizeof(float));
+        inLeft += c; inRight += c; inSampleCount -= c;
+        s->inPos = (s->inPos + c) & (FFTSIZE - 1);
+        s->needed -= c;
+        if (s->needed == 0) process_hop(s);
+    }
+    float* io[COMPONENTS];
+    for (int j = 0; j < COMPONENTS; ++j) io[j] = components[j];
+    while (s->outCount > 0 && outSampleCount < maxOut) {                    // Spleeter4Stems.c:540-581
+        const float* src = s->outq[0] + (size_t)s->outReadOff * COMPONENTS;
+        int c = OUTPUTSEG - s->outReadOff;
+        if (c > maxOut - outSampleCount) c = maxOut - outSampleCount;
+        for (int i = 0; i < c; ++i)
+            for (int j = 0; j < COMPONENTS; ++j) *io[j]++ = *src++;
+        outSampleCount += c;
+        s->outReadOff += c;
+        if (s->outReadOff == OUTPUTSEG) {
+            s->outCount--;
+            s->outReadOff = 0;
+            if (s->outCount > 0) { float* t = s->outq[0]; s->outq[0] = s->outq[1]; s->outq[1] = t; }
+        }
+    }
+}

@@ -23,14 +23,14 @@ def _declared():
     names = set()
     for h in os.listdir(INC):
         txt = "\n".join(ln for ln in open(os.path.join(INC, h)).read().splitlines() if not ln.lstrip().startswith("#"))
-        names |= set(re.findall(r"(?:SRT_API|SPLEETER_API|STFT_API)\s+[\w\s\*]*?\b(\w+)\s*\(", txt))
+        names |= set(re.findall(r"(?:SRT_API|SPLEETER_API|STFT_API|S4S_API)\s+[\w\s\*]*?\b(\w+)\s*\(", txt))
     return names
 
 
 def test_every_declared_symbol_is_exported(lib):
     L, so = lib
     declared = _declared()
-    assert {"srtCreate", "srtForward", "srtSeparate", "initSpleeter", "processSpleeter", "getMaskPtr", "InitSTFT", "stft", "istft"} <= declared
+    assert {"srtCreate", "srtForward", "srtSeparate", "initSpleeter", "processSpleeter", "getMaskPtr", "InitSTFT", "stft", "istft", "Spleeter4StemsInit", "Spleeter4StemsProcessSamples", "Spleeter4StemsFree"} <= declared
     exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines()}
     assert declared <= exported, declared - exported
     # and nothing private leaks: only the three API families are visible
