@@ -158,3 +158,29 @@ def test_separate_end_to_end(oracle, coeffs):
         assert _rel_rms(out[s], ref) <= 1e-4, "stem %d rel rms %g" % (s, _rel_rms(out[s], ref))
         assert np.abs(out[s] - ref).max() <= 1e-4 * peak
     eng.close()
+
+
+def test_chunked_stream_equals_single_batch(oracle, coeffs):
+    """Tile-range chunking (spleeterrt_amd.stream: what long streams and multi-GPU shards use) on the real engine:
+    a 5-tile stream run as one batch == the same stream run as chunks of 2 tiles (+ halo) and stitched."""
+    import torch
+    import spleeterrt_amd as srt
+    from spleeterrt_amd import stream
+    T, F = 64, 512
+    n = 4096 * 70 + 8192 + 700                                # 289 rows -> 5 tiles, ragged
+    L, R = oracle.synth_audio(n, 99, True)
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    big = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=8)
+    small = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=2)
+    for e in (big, small):
+        for s in range(2):
+            e.set_coeff(s, coeffs(s))
+    ref = big.separate(Ld, Rd).cpu().numpy()
+    for world in (1, 2):
+        parts = []
+        for rank in range(world):
+            parts += stream.separate_stream(small, Ld, Rd, rank, world)
+        got = stream.stitch(parts, n, 2)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), "world %d" % world
+    big.close(); small.close()
