@@ -101,6 +101,22 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
     fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
 
+    // the windowed samples of the NEXT frame are loaded while the current frame is transformed
+    float2 nxt[16];
+    auto fetch = [&](int f) {
+        if (f >= p.frames_computed || f >= p.rows_total) return;         // workgroup-uniform
+        const size_t pos = (size_t)f * SRT_HOP;
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int n = tid + 256 * n2;
+            const float w = p.tab.preWin[n];
+            const bool ok = pos + n < p.nsamples;                        // tail frame is zero padded (stftFix.c:460-472)
+            const size_t q = ok ? pos + n : 0;
+            const float l = p.L[q], r = p.R[q];
+            nxt[n2] = f2(ok ? l * w : 0.f, ok ? r * w : 0.f);
+        }
+    };
+    fetch(blockIdx.x * STFT_FPB);
     for (int fi = 0; fi < STFT_FPB; ++fi) {
         const int f = blockIdx.x * STFT_FPB + fi;
         if (f >= p.rows_total) break;
@@ -114,15 +130,10 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
             if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
             continue;
         }
-        const size_t pos = (size_t)f * SRT_HOP;
         float2 v[16];
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            const int n = tid + 256 * n2;
-            const float w = p.tab.preWin[n];
-            const bool ok = pos + n < p.nsamples;        // tail frame is zero padded (stftFix.c:460-472)
-            v[n2] = f2(ok ? p.L[pos + n] * w : 0.f, ok ? p.R[pos + n] * w : 0.f);
-        }
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = nxt[n2];
+        if (fi + 1 < STFT_FPB) fetch(f + 1);
         fft4096(v, s_x, s_tw, tid);
         __syncthreads();
 #pragma unroll
@@ -188,26 +199,37 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
 #pragma unroll
             for (int j = 0; j < 4; ++j) { accL[st][h][j] = 0.0f; accR[st][h][j] = 0.0f; }
 
+    // Software pipeline: the spectrum row and mask rows of the NEXT (frame, stem) pair are in flight while the
+    // current pair is transformed, so the global-load latency is not exposed once per FFT.
+    float2 csl[9], csr[9];
+    float cgl[9], cgr[9];
+    auto fetch = [&](int f, int st, float2 (&sl)[9], float2 (&sr)[9], float (&gl)[9], float (&gr)[9]) {
+        if (f < 0 || f >= p.frames || f >= s1 || st >= nst) return;          // workgroup-uniform
+        const int tile = f / p.T, t = f % p.T, sg = stem0 + st;
+        const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
+        const float2* specR = specL + p.spec_ch_stride;
+        const float* mL = p.masks ? p.masks + ((size_t)(sg * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
+        const float oob = p.oob[sg];                                         // bins >= F: "unaffectedWeight" (main.c:486-493)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = min(tid + 256 * j, 2048), km = min(k, p.F - 1);
+            sl[j] = specL[k]; sr[j] = specR[k];
+            const float a = mL ? mL[km] : 1.0f, b = mL ? mL[tf + km] : 1.0f;
+            gl[j] = k < p.F ? a : oob; gr[j] = k < p.F ? b : oob;
+        }
+    };
+    fetch(max(s0 - 3, 0), 0, csl, csr, cgl, cgr);
     for (int f = s0 - 3; f < s1; ++f) {
         const bool live = f >= 0 && f < p.frames;                    // workgroup-uniform
         if (live) {
-            const int tile = f / p.T, t = f % p.T;
-            const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
-            const float2* specR = specL + p.spec_ch_stride;
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 if (st < nst) {
-                    const int sg = stem0 + st;
-                    const float* mL = p.masks ? p.masks + ((size_t)(sg * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
-                    const float* mR = mL ? mL + tf : nullptr;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) {
                         const int k = tid + 256 * j;
                         if (k <= 2048) {
-                            const float2 sl = specL[k], sr = specR[k];       // re-read per stem: L1/L2 hit, keeps 36 VGPRs free
-                            float gl = p.oob[sg], gr = p.oob[sg];            // bins >= F: "unaffectedWeight" (main.c:486-493)
-                            if (k < p.F) { gl = mL ? mL[k] : 1.0f; gr = mR ? mR[k] : 1.0f; }
-                            const float reL = sl.x * gl, imL = sl.y * gl, reR = sr.x * gr, imR = sr.y * gr;
+                            const float reL = csl[j].x * cgl[j], imL = csl[j].y * cgl[j], reR = csr[j].x * cgr[j], imR = csr[j].y * cgr[j];
                             // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; stored swapped (im,re): inverse-by-forward trick
                             if (k == 0) s_x[0] = f2(reR, reL);                                // a[0] = re[0]           (stftFix.c:556-557)
                             else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);        // rev[2048]: re - im wins (stftFix.c:563-566)
@@ -222,6 +244,9 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
 #pragma unroll
                     for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
                     __syncthreads();
+                    // the staging registers are free again: put the next pair's rows in flight under this FFT
+                    if (st + 1 < nst) fetch(f, st + 1, csl, csr, cgl, cgr);
+                    else fetch(f + 1, 0, csl, csr, cgl, cgr);
                     fft4096(v, s_x, s_tw, tid);
 #pragma unroll
                     for (int k2 = 0; k2 < 16; ++k2) {
@@ -233,6 +258,8 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
                     __syncthreads();
                 }
             }
+        } else if (f + 1 >= 0 && f + 1 < p.frames) {
+            fetch(f + 1, 0, csl, csr, cgl, cgr);                      // first live frame after the (virtual) frames before 0
         }
         // segment f is complete: emit it, then slide the window
         const bool emit = f >= s0;
@@ -262,9 +289,9 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     int G = (nseg + 511) / 512;                       // ~2 workgroups per CU when the stream is long enough
     if (G < 13) G = 13;                               // keep the 3-frame warm-up below ~25 %
     const int blocks = (nseg + G - 1) / G;
-    // two stems per workgroup: 64 accumulator registers + the FFT fit in 256 VGPRs at 2 workgroups per CU (four stems spill)
-    for (int st0 = 0; st0 < p.nstems; st0 += 2) {
-        hipLaunchKernelGGL((srt_istft_ola_kernel<2>), dim3(blocks), dim3(256), 0, s, p, G, st0);
+    // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
+    for (int st0 = 0; st0 < p.nstems; st0 += 1) {
+        hipLaunchKernelGGL((srt_istft_ola_kernel<1>), dim3(blocks), dim3(256), 0, s, p, G, st0);
         if (hipGetLastError() != hipSuccess) return -1;
     }
     return 0;
