@@ -184,3 +184,23 @@ def test_chunked_stream_equals_single_batch(oracle, coeffs):
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), "world %d" % world
     big.close(); small.close()
+
+
+@pytest.mark.parametrize("T,F,stems", [(256, 1536, 1), (64, 576, 2), (128, 2048, 1), (64, 64, 1), (256, 1024, 5)])
+def test_forward_other_geometries(oracle, coeffs, T, F, stems):
+    """Geometries the reference is used with: the VST default (F=1536, T=256, PluginProcessor.cpp:124), the CLI's clamp
+    range 512..2048 (main.c:741-748), a width whose deep levels are not multiples of 4 (falls back to the scalar-staging
+    kernels), the smallest legal tile, and the 5-stem configuration (BASELINE configs[4], fp32 here)."""
+    import torch
+    import spleeterrt_amd as srt
+    eng = _engine(F=F, T=T, stem_modes=(1,) * stems, variant=srt.VARIANT_VST, max_tiles=1)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, 1, T, F, seed=1000 + F)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    check = range(stems) if T * F <= 64 * 1024 else (stems - 1,)          # the oracle needs seconds per large tile
+    for s in check:
+        y = oracle.forward(coeffs(s), x[0], 1, oracle.VARIANT_VST)
+        d = np.abs(masks[s, 0] - y).max()
+        assert d <= MASK_TOL_EXACT, "T=%d F=%d stem %d: max abs %g" % (T, F, s, d)
+    eng.close()
