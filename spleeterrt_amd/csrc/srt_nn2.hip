@@ -406,6 +406,20 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Tuning hook: SRT_TUNE="down2=1,up5=2,..." selects an alternative tile shape for a layer class (measurement only;
+// the defaults below are the measured-best shapes for T=256, F=1024).
+#include <stdlib.h>
+#include <string.h>
+static int tune(const char* key)
+{
+    const char* e = getenv("SRT_TUNE");
+    if (!e) return 0;
+    const char* q = strstr(e, key);
+    if (!q) return 0;
+    q += strlen(key);
+    return *q == '=' ? atoi(q + 1) : 0;
+}
+
 int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4) return 1;
@@ -415,7 +429,14 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
         if (p.stack * p.Cout > 32) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
         return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
     }
-    if (p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);       // down2 (an 8x64 tile / NR = 4 measured 4 % slower)
+    if (p.Cout <= 32) {                                                                  // down2 (an 8x64 tile / NR = 4 measured 4 % slower)
+        switch (tune("down2")) {
+        case 1: return launch_enc2_cfg<32, 1, 32, 1, 8, 1, 4, false>(p, s);
+        case 2: return launch_enc2_cfg<32, 1, 32, 4, 2, 1, 4, false>(p, s);
+        case 3: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 8, false>(p, s);
+        default: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
+        }
+    }
     if (Wo >= 64) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);            // down3 / down4 class
     if (Wo >= 32) return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 4, false>(p, s);            // down5 class
     return launch_enc2_cfg<64, 2, 16, 1, 2, 4, 4, false>(p, s);                          // down6 class
@@ -424,8 +445,24 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
-    if (p.Cout == 16) return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s) : 1;   // up5, class-stacked M (KC = 8: 6 % slower; 8x64 tile: 14 % slower)
-    if (p.Cout <= 32) return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);        // up4 (KC = 8 measured 5 % slower)
+    if (p.Cout == 16) {                                                                  // up5, class-stacked M (KC = 8: 6 % slower; 8x64 tile: 14 % slower)
+        if (!p.wpack2) return 1;
+        switch (tune("up5")) {
+        case 1: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s);
+        case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s);
+        case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+        case 4: return launch_dec2_cfg<32, 1, 32, 1, 4, 1, 4, true>(p, s);
+        default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s);
+        }
+    }
+    if (p.Cout <= 32) {                                                                  // up4 (KC = 8 measured 5 % slower)
+        switch (tune("up4")) {
+        case 1: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, false>(p, s);
+        case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, false>(p, s);
+        case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, false>(p, s);
+        default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
+        }
+    }
     if (p.W >= 32) return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);           // up2 / up3
     return launch_dec2_cfg<64, 2, 16, 1, 2, 2, 4, false>(p, s);                          // up1
 }
