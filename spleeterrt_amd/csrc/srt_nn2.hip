@@ -64,6 +64,46 @@ __device__ __forceinline__ void srt_dma_slab(const float* wp, size_t rowStride, 
     }
 }
 
+
+// one 1-KiB piece of a slab (piece index wave-uniform); used to spread the DMA issue between the MFMAs of a chunk
+template <int NROWS, int BM>
+__device__ __forceinline__ void srt_dma_piece(const float* wp, size_t rowStride, float* lds, int piece, int lane)
+{
+    constexpr int RPI = 256 / BM, NPIECE = (NROWS + RPI - 1) / RPI;
+    if (piece < NPIECE) {
+        const int row = min(piece * RPI + lane / (BM / 4), NROWS - 1);
+        srt_dma16(wp + (size_t)row * rowStride + (lane % (BM / 4)) * 4, lds + piece * 256);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- XCD-aware block order
+// The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with a private 4 MiB L2.  With the plain
+// (spatial, M-block, instance) order every XCD sees the weight slabs of several (stem, M-block) pairs at once (13 MB for
+// up2) and streams them from MALL/HBM for every workgroup (ablation: +8 % when the weight/patch traffic is removed).
+// Here the launch is 1-D and XCD x walks the x-th CONTIGUOUS chunk of the (stem, M-block)-major order, so at any time an
+// XCD works on one weight slab (1.6-3.3 MB, L2 resident) and on neighbouring pixel tiles.  Speed only: any placement
+// gives the same result.  Returns the position in (stem, M-block)-major order.
+__device__ __forceinline__ int srt_xcd_order(int total)
+{
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int q = total >> 3, r = total & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+struct SrtBlockCoord { int sp, mblk, stem, grp; };
+// order: w = (stem, mblk) slowest, then instance group, then spatial tile (fastest: neighbours share halo rows)
+__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp)
+{
+    const int pos = srt_xcd_order(nsp * nmb * nstem * ngrp);
+    SrtBlockCoord c;
+    c.sp = pos % nsp;
+    const int t = pos / nsp;
+    c.grp = t % ngrp;
+    const int w = t / ngrp;
+    c.mblk = w % nmb;
+    c.stem = w / nmb;
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------- encoder v2
 template <int TW, int SW> struct Enc2Pad {
     static constexpr int base = TW + 4;                 // halves per parity plane of a staged row
@@ -92,27 +132,30 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
-    const int tilesX = (Wo + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
-    const int m0 = blockIdx.y * BM;
+    const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
-    const int stem = STEMSTACK ? 0 : blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const int mtot = STEMSTACK ? p.stack * p.Cout : p.Cout;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (mtot + BM - 1) / BM, STEMSTACK ? 1 : p.nstems, groups);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
+    const int m0 = bc.mblk * BM;
+    const int stem = bc.stem, tile0 = bc.grp * NI;
     const size_t hw = (size_t)p.H * p.W;
     const int CPW = STEMSTACK ? p.CP2 : p.CP;
     const float* wp = (STEMSTACK ? p.wpack2 : p.wpack + stem * p.wpack_stem) + m0;
 
     float4 pin[NLD];
+    auto load_patch_elem = [&](int c0, int i) {
+        const int e = min(tid + i * 256, NF4 - 1);
+        const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+        const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
+        const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+        const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
+        pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     auto load_patch = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = min(tid + i * 256, NF4 - 1);
-            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-            const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
-            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
-            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
-            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NLD; ++i) load_patch_elem(c0, i);
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -152,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         store_patch();
         __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
         const float* sw = s_w + (ch & 1) * WSLAB;
-        if (ch + 1 < nchunks) {
+        if (ch + 1 < nchunks) {       // issued up front; spreading the pieces between the MFMAs measured no gain
             srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
             load_patch((ch + 1) * KC);
         }
@@ -215,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 
 // ------------------------------------------------------------------------------------------- decoder v2
 // CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK>
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
@@ -235,27 +278,29 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int tilesX = (p.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
-    const int m0 = blockIdx.y * BM;
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
-    const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, CLASSSTACK ? 1 : (p.Cout + BM - 1) / BM, p.nstems, groups);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
+    const int m0 = bc.mblk * BM;
+    const int stem = bc.stem, tile0 = bc.grp * NI;
     const size_t hw = (size_t)p.H * p.W;
     const int CPW = CLASSSTACK ? 32 : p.CP;
     const float* wp = (CLASSSTACK ? p.wpack2 + stem * p.wpack2_stem : p.wpack + stem * p.wpack_stem) + m0;
 
     float4 pin[NLD];
+    auto load_patch_elem = [&](int c0, int i) {
+        const int e = min(tid + i * 256, NF4 - 1);
+        const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+        const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
+        const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
+        const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
+        pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     auto load_patch = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = min(tid + i * 256, NF4 - 1);
-            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
-            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
-            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
-            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NLD; ++i) load_patch_elem(c0, i);
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -292,12 +337,12 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
     load_patch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_patch();
-        __syncthreads();
+        if ((ABL != 1 && ABL != 4) || ch == 0) store_patch();
+        if (ABL != 2) __syncthreads();
         const float* sw = s_w + (ch & 1) * WSLAB;
-        if (ch + 1 < nchunks) {
-            srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * NTAP * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
-            load_patch((ch + 1) * KC);
+        if (ch + 1 < nchunks && ABL != 1) {
+            if (ABL != 5) srt_dma_slab<WROWS, BM>((ABL == 6 ? wp : wp + (size_t)(ch + 1) * KC * NTAP * CPW), CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            if (ABL != 4) load_patch((ch + 1) * KC);
         }
 #pragma unroll
         for (int cp = 0; cp < KC / 2; ++cp) {
@@ -305,7 +350,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 #pragma unroll
             for (int sh = 0; sh < 9; ++sh)
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) b[sh][nr] = s_in[boff[nr] + 2 * cp * CHS + (sh / 3) * ROWS + (sh % 3)];
+                for (int nr = 0; nr < NR; ++nr) b[sh][nr] = ABL == 3 ? (float)(sh + nr + ch) : s_in[boff[nr] + 2 * cp * CHS + (sh / 3) * ROWS + (sh % 3)];
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 int cls, sh;
@@ -319,7 +364,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
                 }
                 float a[MR];
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[mr] = sw[aoff + (2 * cp * NTAP + t) * BM + mr * 32];
+                for (int mr = 0; mr < MR; ++mr) a[mr] = ABL == 3 ? (float)(t + cp) : sw[aoff + (2 * cp * NTAP + t) * BM + mr * 32];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -327,7 +372,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
                         acc[cls][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[sh][nr], acc[cls][mr][nr], 0, 0, 0);
             }
         }
-        __syncthreads();
+        if (ABL != 2) __syncthreads();
     }
 
     const float* bias = p.bias + stem * p.coeff_stem;
@@ -393,7 +438,7 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     const int Ho = p.H / 2, Wo = p.W / 2;
     const int mtot = STK ? p.stack * p.Cout : p.Cout;
-    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH), (mtot + BM - 1) / BM, (STK ? 1 : p.nstems) * ((p.ntiles + NI - 1) / NI));
+    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((mtot + BM - 1) / BM) * (STK ? 1 : p.nstems) * ((p.ntiles + NI - 1) / NI));
     hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -401,7 +446,7 @@ template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
-    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), STK ? 1 : (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * (STK ? 1 : (p.Cout + BM - 1) / BM) * p.nstems * ((p.ntiles + NI - 1) / NI));
     hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -463,6 +508,20 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
         default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
         }
     }
-    if (p.W >= 32) return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);           // up2 / up3
+    if (p.W >= 32) {                                                                     // up2 / up3
+        const int abl = tune("abl");                                                     // ablation builds (wrong results, timing only)
+        if (abl) {
+            constexpr int TW = 32, TH = 4;
+            dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
+            if (abl == 1) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 1>), grid, dim3(256), 0, s, p);
+            if (abl == 2) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 2>), grid, dim3(256), 0, s, p);
+            if (abl == 3) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 3>), grid, dim3(256), 0, s, p);
+            if (abl == 4) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
+            if (abl == 5) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
+            if (abl == 6) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 6>), grid, dim3(256), 0, s, p);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);
+    }
     return launch_dec2_cfg<64, 2, 16, 1, 2, 2, 4, false>(p, s);                          // up1
 }
