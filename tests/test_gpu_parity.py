@@ -204,3 +204,40 @@ def test_forward_other_geometries(oracle, coeffs, T, F, stems):
         d = np.abs(masks[s, 0] - y).max()
         assert d <= MASK_TOL_EXACT, "T=%d F=%d stem %d: max abs %g" % (T, F, s, d)
     eng.close()
+
+
+@pytest.mark.parametrize("n", [4096, 4097, 4096 + 1023, 8192 + 5])
+def test_minimum_length_signals(oracle, coeffs, n):
+    """Shortest inputs the reference accepts (one transform; below 4096 samples it underflows, stftFix.c:378):
+    1 computed frame, the remaining rows stay zero, the single tile is almost entirely padding."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    L, R = oracle.synth_audio(n, 3, True)
+    eng = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1)
+    eng.set_coeff(0, coeffs(0))
+    out = eng.separate(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    re, im = oracle.stft(L, R)
+    oracle.process_spectrogram(coeffs(0), re, im, F, T, 1, oracle.VARIANT_VST, 0.1)
+    ref = oracle.istft(re, im)
+    assert out.shape[2] == ref.shape[1]
+    assert np.abs(out[0] - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
+    eng.close()
+
+
+def test_rejects_bad_arguments():
+    import torch
+    import spleeterrt_amd as srt
+    with pytest.raises(srt.EngineError):
+        _engine(F=500, T=64, stem_modes=(1,))                 # F, T must be multiples of 64 (spleeter.c:113-119)
+    eng = _engine(F=512, T=64, stem_modes=(1,), max_tiles=1)
+    x = torch.zeros((1, 2, 64, 512), device="cuda")
+    with pytest.raises(srt.EngineError):
+        eng.forward(x)                                        # weights not set
+    z = torch.zeros(1000, device="cuda")
+    with pytest.raises(srt.EngineError):
+        eng.separate(z, z)                                    # shorter than one frame
+    big = torch.zeros(64 * 1024 * 3, device="cuda")
+    with pytest.raises(srt.EngineError):
+        eng.stft(big, big)                                    # more tiles than max_tiles
+    eng.close()
