@@ -431,6 +431,145 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- decoder, Cout = 16 (up5)
+// v_mfma_f32_16x16x4_f32 form: M = the 16 output channels exactly (no padded or stacked rows), N = 16 pixels of one row,
+// k-quad = 4 input channels of one tap.  Same rate per FLOP as the 32x32x2 form, but 25 instead of 30 (class-stacked)
+// 32-row-equivalents per channel quad.  A operands come from the plain K-major pack [Cin][25][CP] (CP = 32, first 16 used).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NSX, int NSY, int KC>                      // tile = NSY rows x (NSX*16) columns of input-resolution pixels
+__global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p)
+{
+    constexpr int TW = NSX * 16, TH = NSY, NS = NSX * NSY, NR = NS / 4;
+    static_assert(NS % 4 == 0 && KC == 4, "tile");
+    constexpr int PH = TH + 2, RW4 = (TW + 8) / 4, ROWS = TW + 8, CHS = PH * ROWS;
+    constexpr int NF4 = KC * PH * RW4, NLD = (NF4 + 255) / 256;
+    constexpr int WSLAB = KC * 25 * 16;                                     // 1600 floats per chunk
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
+    float* s_in = s_mem;
+    float* s_w = s_mem + KC * CHS;
+
+    const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, 1, p.nstems, p.ntiles);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
+    const int stem = bc.stem, tile = bc.grp;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* wp = p.wpack + stem * p.wpack_stem;                        // [Cin][25][CP]
+
+    float4 pin[NLD];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + i * 256, NF4 - 1);
+            const int j = e % RW4, ru = e / RW4, r = ru % PH, c = ru / PH;
+            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j;
+            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const float* src = srt_src_channel(p, stem, tile, c0 + c, hw);
+            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
+            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NF4) {
+                const int j = e % RW4, ru = e / RW4, r = ru % PH, c = ru / PH;
+                *reinterpret_cast<float4*>(s_in + c * CHS + r * ROWS + 4 * j) = pin[i];
+            }
+        }
+    };
+    // weights of a chunk: KC*25 rows of 16 floats; threads 0..399 move one float4 each (plain loads: the slab is 6.4 KB)
+    float4 pwt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_w = [&](int c0) {
+        const int e = min(tid, KC * 25 * 4 - 1) , row = e >> 2, q = e & 3;
+        pwt = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + q * 4);
+    };
+    auto store_w = [&](int buf) {
+        if (tid < KC * 25 * 4) *reinterpret_cast<float4*>(s_w + buf * WSLAB + tid * 4) = pwt;
+    };
+    // threads 256..399 do not exist (256-thread block): second pass for the remaining 144 float4
+    float4 pwt2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_w2 = [&](int c0) {
+        const int e = min(tid + 256, KC * 25 * 4 - 1), row = e >> 2, q = e & 3;
+        pwt2 = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + q * 4);
+    };
+    auto store_w2 = [&](int buf) {
+        if (tid + 256 < KC * 25 * 4) *reinterpret_cast<float4*>(s_w + buf * WSLAB + (tid + 256) * 4) = pwt2;
+    };
+
+    f32x4 acc[4][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr, sy = s / NSX, sx = s % NSX;
+        boff[nr] = kq * CHS + sy * ROWS + sx * 16 + l15 + 3;               // + (1+dy)*ROWS + (1+dx) -> column b+dx+4
+    }
+    const int aoff = kq * 25 * 16 + l15;
+
+    const int nchunks = p.Cin / KC;
+    load_patch(0); load_w(0); load_w2(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        store_patch(); store_w(ch & 1); store_w2(ch & 1);
+        __syncthreads();
+        const float* sw = s_w + (ch & 1) * WSLAB;
+        if (ch + 1 < nchunks) { load_patch((ch + 1) * KC); load_w((ch + 1) * KC); load_w2((ch + 1) * KC); }
+        float b[9][NR];
+#pragma unroll
+        for (int sh = 0; sh < 9; ++sh)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b[sh][nr] = s_in[boff[nr] + (sh / 3) * ROWS + (sh % 3)];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int ky = t / 5, kx = t % 5, py = (ky + 1) & 1, px = (kx + 1) & 1;
+            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+            const int cls = py * 2 + px, sh = (dy + 1) * 3 + (dx + 1);
+            const float a = sw[aoff + t * 16];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[cls][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[sh][nr], acc[cls][nr], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const float* bias = p.bias + stem * p.coeff_stem;
+    const float* scale = p.bnScale + stem * p.coeff_stem;
+    const float* shift = p.bnShift + stem * p.coeff_stem;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float bi[4], sc[4], sf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int co = 4 * kq + r; bi[r] = bias[co]; sc[r] = scale[co]; sf[r] = shift[co]; }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr, sy = s / NSX, sx = s % NSX;
+        const int a = ty0 + sy, b0 = tx0 + sx * 16 + l15;
+        if (a < p.H && b0 < p.W) {
+            float* o = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(2 * a) * Wo + 2 * b0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * kq + r;                                   // D layout: row = 4*(lane>>4) + r, col = lane&15
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    float2 v;
+                    v.x = srt_dec_epilogue(acc[py * 2 + 0][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                    v.y = srt_dec_epilogue(acc[py * 2 + 1][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                    *reinterpret_cast<float2*>(o + (size_t)co * ohw + (size_t)py * Wo) = v;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- dispatch
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
@@ -490,9 +629,18 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
-    if (p.Cout == 16) {                                                                  // up5, class-stacked M (KC = 8: 6 % slower; 8x64 tile: 14 % slower)
+    if (p.Cout == 16) {                                                                  // up5
+        const int v = tune("up5");
+        if (v >= 10) {                                                                   // exact-M 16x16x4 form: measured 2-3 % SLOWER than class-stacking (both ~100 TFLOP/s: the layer is epilogue/staging bound), kept for measurement
+            constexpr int NSX = 4, NSY = 8;                                              // 8 rows x 64 columns
+            dim3 grid(((p.W + 63) / 64) * ((p.H + NSY - 1) / NSY) * p.nstems * p.ntiles);
+            if (v == 11) hipLaunchKernelGGL((srt_dec16_kernel<8, 4, 4>), dim3(((p.W + 127) / 128) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+            else if (v == 12) hipLaunchKernelGGL((srt_dec16_kernel<2, 16, 4>), dim3(((p.W + 31) / 32) * ((p.H + 15) / 16) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((srt_dec16_kernel<NSX, NSY, 4>), grid, dim3(256), 0, s, p);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
         if (!p.wpack2) return 1;
-        switch (tune("up5")) {
+        switch (v) {                                                                     // class-stacked 32x32x2 forms (83 % row efficiency)
         case 1: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s);
         case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s);
         case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
