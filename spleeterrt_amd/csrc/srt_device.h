@@ -12,7 +12,9 @@ __device__ __forceinline__ float srt_act(float x, int kind, int variant)
     if (kind == SRT_ACT_LEAKY) return x >= 0.0f ? x : 0.2f * x;          // Executable/spleeter.c:43-46
     if (kind == SRT_ACT_RELU) return x >= 0.0f ? x : 0.0f;               // :47-50
     if (variant == 0 && x < -15.0f) return -1.0f;                        // :51-56 (VST flavour has no clamp)
-    return x >= 0.0f ? x : expf(x) - 1.0f;
+    // __expf = v_exp_f32(x * log2e): |abs error| <= e^x * |x| * 6e-8 <= 2.2e-8 on x < 0, far below the fp32 noise of the
+    // dot product feeding it, at ~1/5 of the instructions of expf (the epilogue evaluates it for every output element)
+    return x >= 0.0f ? x : __expf(x) - 1.0f;
 }
 __device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, int act, int variant)
 {
