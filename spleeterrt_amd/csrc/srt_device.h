@@ -16,13 +16,42 @@ __device__ __forceinline__ float srt_act(float x, int kind, int variant)
     // dot product feeding it, at ~1/5 of the instructions of expf (the epilogue evaluates it for every output element)
     return x >= 0.0f ? x : __expf(x) - 1.0f;
 }
+// Branch-free form for the MFMA epilogues (which evaluate it for every accumulator element): the activation kind is
+// launch-uniform, so it is folded once into three scalars and every element costs one v_exp_f32 + a few VALU ops instead
+// of a chain of scalar branches (the branchy form was 88 % of the decoder kernel's instructions).
+//   x >= 0 ? x : lin*x + ue*((x < thr) ? -1 : exp(x) - 1)      leaky: (0.2, 0, -inf)  relu: (0, 0, -inf)  elu: (0, 1, -15 | -inf)
+struct SrtAct { float lin, ue, thr; };
+__device__ __forceinline__ SrtAct srt_act_params(int kind, int variant)
+{
+    SrtAct a;
+    a.lin = kind == SRT_ACT_LEAKY ? 0.2f : 0.0f;
+    a.ue = kind == SRT_ACT_ELU ? 1.0f : 0.0f;
+    a.thr = (kind == SRT_ACT_ELU && variant == 0) ? -15.0f : -__builtin_huge_valf();
+    return a;
+}
+__device__ __forceinline__ float srt_act_apply(float x, const SrtAct& a)
+{
+    const float e = x < a.thr ? -1.0f : __expf(fminf(x, 0.0f)) - 1.0f;
+    const float neg = a.lin * x + a.ue * e;
+    return x >= 0.0f ? x : neg;
+}
+__device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, const SrtAct& a)
+{
+    return srt_act_apply(scale * v + shift, a);                          // spleeter.c:188: act(bn[C+s]*v + bn[s])
+}
+__device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float scale, float shift, const SrtAct& a)
+{
+    const float v = srt_act_apply(acc + bias, a);                        // spleeter.c:244-245: activation BEFORE BN
+    return scale * v + shift;
+}
+// branchy forms (naive cross-check kernels)
 __device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, int act, int variant)
 {
-    return srt_act(scale * v + shift, act, variant);                     // spleeter.c:188: act(bn[C+s]*v + bn[s])
+    return srt_act(scale * v + shift, act, variant);
 }
 __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float scale, float shift, int act, int variant)
 {
-    float v = srt_act(acc + bias, act, variant);                         // spleeter.c:244-245: activation BEFORE BN
+    float v = srt_act(acc + bias, act, variant);
     return scale * v + shift;
 }
 #pragma clang fp contract(fast)

@@ -227,6 +227,7 @@ template <int TW, int SW> struct EncPad {
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
                 if (pix_ok && m < p.Cout) {
                     const float v = acc[mr][nr][r] + bi[r];
                     p.outRaw[obase + (size_t)m * ohw] = v;
-                    if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], p.act, p.variant);
+                    if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], actp);
                 }
             }
         }
@@ -375,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -513,8 +515,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 #pragma unroll
                     for (int py = 0; py < 2; ++py) {
                         float2 v;
-                        v.x = srt_dec_epilogue(acc[py * 2 + 0][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
-                        v.y = srt_dec_epilogue(acc[py * 2 + 1][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                        v.x = srt_dec_epilogue(acc[py * 2 + 0][mr][nr][r], bi[r], sc[r], sf[r], actp);
+                        v.y = srt_dec_epilogue(acc[py * 2 + 1][mr][nr][r], bi[r], sc[r], sf[r], actp);
                         *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
                     }
                 }
@@ -533,6 +535,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 template <int TH, int TW, int CIN>
 __global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
     __shared__ float s_col[25 * NPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -596,8 +599,8 @@ __global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 float2 v;
-                v.x = srt_dec_epilogue(o[py * 2 + 0], bi, sc, sf, p.act, p.variant);
-                v.y = srt_dec_epilogue(o[py * 2 + 1], bi, sc, sf, p.act, p.variant);
+                v.x = srt_dec_epilogue(o[py * 2 + 0], bi, sc, sf, actp);
+                v.y = srt_dec_epilogue(o[py * 2 + 1], bi, sc, sf, actp);
                 *reinterpret_cast<float2*>(out + (size_t)(2 * ga + py) * Wo + 2 * gb) = v;
             }
         }

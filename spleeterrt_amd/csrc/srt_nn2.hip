@@ -114,6 +114,7 @@ template <int TW, int SW> struct Enc2Pad {
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                 if (pix_ok && m < mlimit) {
                     const float v = acc[mr][nr][r] + bi[r];
                     p.outRaw[ob[r] + pbase] = v;
-                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], p.act, p.variant);
+                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], actp);
                 }
             }
         }
@@ -261,6 +262,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -406,8 +408,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 #pragma unroll
                         for (int py = 0; py < 2; ++py) {
                             float2 v;
-                            v.x = srt_dec_epilogue(acc[py][0][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
-                            v.y = srt_dec_epilogue(acc[py][0][nr][r + 8], bi[r], sc[r], sf[r], p.act, p.variant);
+                            v.x = srt_dec_epilogue(acc[py][0][nr][r], bi[r], sc[r], sf[r], actp);
+                            v.y = srt_dec_epilogue(acc[py][0][nr][r + 8], bi[r], sc[r], sf[r], actp);
                             *reinterpret_cast<float2*>(p.outAct + obase + (size_t)co * ohw + (size_t)py * Wo) = v;
                         }
                     }
@@ -420,8 +422,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 #pragma unroll
                         for (int py = 0; py < 2; ++py) {
                             float2 v;
-                            v.x = srt_dec_epilogue(acc[(py * 2 + 0) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
-                            v.y = srt_dec_epilogue(acc[(py * 2 + 1) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                            v.x = srt_dec_epilogue(acc[(py * 2 + 0) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
+                            v.y = srt_dec_epilogue(acc[(py * 2 + 1) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
                             *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
                         }
                     }
@@ -440,6 +442,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NSX, int NSY, int KC>                      // tile = NSY rows x (NSX*16) columns of input-resolution pixels
 __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p)
 {
+    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int TW = NSX * 16, TH = NSY, NS = NSX * NSY, NR = NS / 4;
     static_assert(NS % 4 == 0 && KC == 4, "tile");
     constexpr int PH = TH + 2, RW4 = (TW + 8) / 4, ROWS = TW + 8, CHS = PH * ROWS;
@@ -561,8 +564,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
                     float2 v;
-                    v.x = srt_dec_epilogue(acc[py * 2 + 0][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
-                    v.y = srt_dec_epilogue(acc[py * 2 + 1][nr][r], bi[r], sc[r], sf[r], p.act, p.variant);
+                    v.x = srt_dec_epilogue(acc[py * 2 + 0][nr][r], bi[r], sc[r], sf[r], actp);
+                    v.y = srt_dec_epilogue(acc[py * 2 + 1][nr][r], bi[r], sc[r], sf[r], actp);
                     *reinterpret_cast<float2*>(o + (size_t)co * ohw + (size_t)py * Wo) = v;
                 }
             }
@@ -645,6 +648,8 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
         case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s);
         case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
         case 4: return launch_dec2_cfg<32, 1, 32, 1, 4, 1, 4, true>(p, s);
+        case 5: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 8, true>(p, s);
+        case 6: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 8, true>(p, s);
         default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s);
         }
     }
