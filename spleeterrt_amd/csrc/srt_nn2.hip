@@ -621,6 +621,9 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
         case 1: return launch_enc2_cfg<32, 1, 32, 1, 8, 1, 4, false>(p, s);
         case 2: return launch_enc2_cfg<32, 1, 32, 4, 2, 1, 4, false>(p, s);
         case 3: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 8, false>(p, s);
+        case 4: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, false>(p, s);
+        case 5: return launch_enc2_cfg<32, 1, 32, 1, 4, 1, 4, false>(p, s);
+        case 6: return launch_enc2_cfg<32, 1, 32, 2, 2, 1, 4, false>(p, s);
         default: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
         }
     }
@@ -634,8 +637,10 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
     if (p.W % 4 || p.Cout < 16) return 1;
     if (p.Cout == 16) {                                                                  // up5
         const int v = tune("up5");
-        if (v == 0 || v >= 10) {             // default: exact-M 16x16x4 form, 4 rows x 128 columns (1.91 ms vs 2.07 class-stacked)
-            if (v == 10) hipLaunchKernelGGL((srt_dec16_kernel<4, 8, 4>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+        if (v == 0 || v >= 10) {             // default: exact-M 16x16x4 form, 4 rows x 64 columns (1.83 ms; 4x128: 1.91; class-stacked 32x32x2: 2.07)
+            if (v == 0 || v == 13) hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 4>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+            else if (v == 14) hipLaunchKernelGGL((srt_dec16_kernel<8, 2, 4>), dim3(((p.W + 127) / 128) * ((p.H + 1) / 2) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+            else if (v == 10) hipLaunchKernelGGL((srt_dec16_kernel<4, 8, 4>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
             else if (v == 12) hipLaunchKernelGGL((srt_dec16_kernel<2, 16, 4>), dim3(((p.W + 31) / 32) * ((p.H + 15) / 16) * p.nstems * p.ntiles), dim3(256), 0, s, p);
             else hipLaunchKernelGGL((srt_dec16_kernel<8, 4, 4>), dim3(((p.W + 127) / 128) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
             return hipGetLastError() == hipSuccess ? 0 : -1;
