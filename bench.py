@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tiles", type=int, default=TILES)
     ap.add_argument("--impl", default="mfma")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f16x2"],
+                    help="conv contraction arithmetic; the headline metric is f32 (other modes are separate, labelled configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0)
     a = ap.parse_args()
@@ -142,7 +144,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
     eng = srt.Engine(F=F, T=T, stem_modes=(1,) * STEMS, oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST,
-                     max_tiles=a.tiles, impl=srt.IMPL_NAIVE if a.impl == "naive" else srt.IMPL_MFMA, device=dev)
+                     max_tiles=a.tiles, impl=srt.IMPL_NAIVE if a.impl == "naive" else srt.IMPL_MFMA, device=dev,
+                     precision={"f32": srt.PREC_F32, "f16": srt.PREC_F16, "f16x2": srt.PREC_F16X2}[a.precision])
     # weights: rank 0 creates them, one RCCL broadcast per blob (the only collective on this path)
     for s in range(STEMS):
         w = synth_weights(s, dev) if rank == 0 else torch.empty(9822725, device=dev)
@@ -192,7 +195,7 @@ def main():
         # achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the engine's stream)
         sym_ms, sym_flop, sym_n = {}, {}, {}
         for k in avg:
-            if k in LAYER_FLOP and (a.impl == "mfma" and a.tiles == TILES):
+            if k in LAYER_FLOP and (a.impl == "mfma" and a.tiles == TILES and a.precision == "f32"):
                 sy = LAYER_SYMBOL[k]
             else:
                 sy = k
@@ -215,11 +218,13 @@ def main():
             "metric": "x_realtime (4-stem separation, 44.1 kHz stereo, PCM->stems resident in HBM); frames_per_s alongside",
             "value": fps * HOP / FS, "unit": "x real-time", "frames_per_s": fps,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "f16": "f16 products, f32 accumulate (conv only; STFT/iSTFT f32)", "f16x2": "f16x2 split products (exact in f32), f32 accumulate"}[a.precision],
+            "data": "synthetic",
             "config": {"workload": "4-stem, fp32, batch=%d spectrogram tiles of %dx%d per GPU (BASELINE configs[2]); "
                                    "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, rows, rows * HOP / FS),
                        "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
-                       "impl": a.impl},
+                       "impl": a.impl, "precision": a.precision},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc.json)",
                          "flop_per_launch": dom_flop, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],

@@ -31,6 +31,9 @@ extern "C" {
 #define SRT_VARIANT_VST 1   /* exact sigmoid, plain ELU (VST/Source/spleeter.c:56-77) */
 #define SRT_IMPL_MFMA   0   /* MFMA implicit-GEMM kernels (product path) */
 #define SRT_IMPL_NAIVE  1   /* one-thread-per-output HIP kernels (debug cross-check, still GPU) */
+#define SRT_PREC_F32    0   /* v_mfma_f32_32x32x2_f32: exact fp32 products (default; the headline path) */
+#define SRT_PREC_F16    1   /* v_mfma_f32_32x32x16_f16, activations rounded to fp16 (BASELINE configs[4]; mask tolerance 2e-2) */
+#define SRT_PREC_F16X2  2   /* same MFMA, activations split hi+lo: products exact in fp32 when the weights are fp16-representable */
 
 typedef struct srt_engine srt_engine;
 
@@ -43,6 +46,7 @@ typedef struct srt_config {
     int   variant;                  /* SRT_VARIANT_* */
     int   max_tiles;                /* capacity: tiles per batch */
     int   impl;                     /* SRT_IMPL_* */
+    int   precision;                /* SRT_PREC_*: arithmetic of the conv contraction (accumulation and everything else is fp32) */
 } srt_config;
 
 SRT_API int  srtCreate(const srt_config *cfg, void *stream, srt_engine **out);

@@ -7,6 +7,7 @@ SO = os.path.join(PKG, "libspleeterrt_amd.so")
 MAX_STEMS = 8
 VARIANT_EXE, VARIANT_VST = 0, 1
 IMPL_MFMA, IMPL_NAIVE = 0, 1
+PREC_F32, PREC_F16, PREC_F16X2 = 0, 1, 2
 COEFF_FLOATS = 9822725
 SPEC_LD = 2052
 
@@ -17,7 +18,7 @@ class EngineError(RuntimeError):
 
 class _Config(C.Structure):
     _fields_ = [("F", C.c_int), ("T", C.c_int), ("n_stems", C.c_int), ("stem_mode", C.c_int * MAX_STEMS),
-                ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int)]
+                ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int), ("precision", C.c_int)]
 
 
 _lib = None
@@ -65,7 +66,7 @@ class Engine:
     """One engine per (device, stream): nstems sub-networks evaluated over batches of T x F spectrogram tiles."""
 
     def __init__(self, F=1024, T=256, stem_modes=(1, 1, 1, 1), oob_weights=None, variant=VARIANT_EXE, max_tiles=1,
-                 impl=IMPL_MFMA, device=None):
+                 impl=IMPL_MFMA, device=None, precision=PREC_F32):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: spleeterrt_amd has no CPU path")
@@ -76,6 +77,7 @@ class Engine:
         self.F, self.T, self.S, self.max_tiles, self.variant = F, T, len(stem_modes), max_tiles, variant
         cfg = _Config()
         cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.impl = F, T, self.S, variant, max_tiles, impl
+        cfg.precision = precision
         for i, m in enumerate(stem_modes):
             cfg.stem_mode[i] = int(m)
             cfg.oob_weight[i] = 0.1 if oob_weights is None else float(oob_weights[i])

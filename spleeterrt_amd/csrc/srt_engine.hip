@@ -54,6 +54,8 @@ struct srt_engine {
     float* coeff_all;                                  // [n_stems][SRT_COEFF_STRIDE]
     float* wpack_down[6]; float* wpack_up[6];          // per layer: [n_stems][Cin*25*CP]
     size_t wpack_down_stem[6], wpack_up_stem[6];
+    uint16_t* wpack16_down[6]; uint16_t* wpack16_up[6];  // fp16-MFMA packs [n_stems][Cin/16][25][2][CP][8] (precision != F32 only)
+    size_t wpack16_down_stem[6], wpack16_up_stem[6];
     float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     bool   have_coeff[SRT_MAX_STEMS];
@@ -89,6 +91,7 @@ struct TimerScope {
 static void free_all(srt_engine* e)
 {
     if (e->coeff_all) hipFree(e->coeff_all);
+    for (int i = 0; i < 6; ++i) { if (e->wpack16_down[i]) hipFree(e->wpack16_down[i]); if (e->wpack16_up[i]) hipFree(e->wpack16_up[i]); }
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
@@ -107,6 +110,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "srtCreate: no HIP device (this library has no CPU path)");
     srt_engine* e = new srt_engine();
+    memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->act, 0, sizeof e->act); memset(e->up, 0, sizeof e->up);
@@ -116,6 +120,15 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     const size_t S = cfg->n_stems, NT = cfg->max_tiles, HW = (size_t)cfg->T * cfg->F;
 #define EALLOC(ptr, nfloats) do { if (hipMalloc((void**)&(ptr), (nfloats) * sizeof(float)) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); } } while (0)
     EALLOC(e->coeff_all, S * SRT_COEFF_STRIDE);
+    if (cfg->precision != SRT_PREC_F32) {
+        for (int i = 0; i < 6; ++i) {
+            const LayerOff& D = e->lo.down[i]; const LayerOff& U = e->lo.up[i];
+            e->wpack16_down_stem[i] = D.cin % 16 ? 0 : (size_t)(D.cin / 16) * 400 * D.cp;      // halves
+            e->wpack16_up_stem[i] = U.cin % 16 ? 0 : (size_t)(U.cin / 16) * 400 * U.cp;
+            if (e->wpack16_down_stem[i] && hipMalloc((void**)&e->wpack16_down[i], S * e->wpack16_down_stem[i] * 2) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); }
+            if (e->wpack16_up_stem[i] && hipMalloc((void**)&e->wpack16_up[i], S * e->wpack16_up_stem[i] * 2) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); }
+        }
+    }
     EALLOC(e->wpack2_d1, (size_t)2 * 25 * 128);
     EALLOC(e->wpack2_u5, S * 64 * 15 * 32);
     for (int i = 0; i < 6; ++i) {
@@ -174,6 +187,8 @@ static int pack_stem(srt_engine* e, int stem)
         const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
         if (srt_launch_pack_enc(c + D.w, e->wpack_down[i] + stem * e->wpack_down_stem[i], D.cin, D.cout, D.cp, e->stream)) return fail(-2, "pack launch failed");
         if (srt_launch_pack_dec(c + U.w, e->wpack_up[i] + stem * e->wpack_up_stem[i], U.cin, U.cout, U.cp, e->stream)) return fail(-2, "pack launch failed");
+        if (e->wpack16_down[i] && srt_launch_pack16(c + D.w, e->wpack16_down[i] + stem * e->wpack16_down_stem[i], D.cin, D.cout, D.cp, 0, e->stream)) return fail(-2, "pack launch failed");
+        if (e->wpack16_up[i] && srt_launch_pack16(c + U.w, e->wpack16_up[i] + stem * e->wpack16_up_stem[i], U.cin, U.cout, U.cp, 1, e->stream)) return fail(-2, "pack launch failed");
     }
     if (srt_launch_pack_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack2_u5 + (size_t)stem * 64 * 15 * 32, 64, 16, e->stream))
         return fail(-2, "pack launch failed");
@@ -245,7 +260,13 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             }
             snprintf(nm, sizeof nm, "down%d", i + 1);
             TimerScope ts(e, nm);
-            int rc2 = e->cfg.impl == SRT_IMPL_MFMA ? srt_launch_enc2(p, e->stream) : 1;
+            int rc2 = 1;
+            if (e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_down[i]) {
+                p.wpack16 = e->wpack16_down[i] + (size_t)s0 * e->wpack16_down_stem[i]; p.wpack16_stem = e->wpack16_down_stem[i];
+                p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
+                rc2 = srt_launch_enc_f16(p, e->stream);
+            }
+            if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_enc2(p, e->stream);
             if (rc2 < 0) return fail(-2, "encoder launch failed");
             if (rc2 == 1 && srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
         }
@@ -271,7 +292,13 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             if (i == 4) { p.wpack2 = e->wpack2_u5 + (size_t)s0 * 64 * 15 * 32; p.wpack2_stem = 64 * 15 * 32; p.CP2 = 32; }
             snprintf(nm, sizeof nm, "up%d", i + 1);
             TimerScope ts(e, nm);
-            int rc2 = e->cfg.impl == SRT_IMPL_MFMA ? srt_launch_dec2(p, e->stream) : 1;
+            int rc2 = 1;
+            if (e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_up[i]) {
+                p.wpack16 = e->wpack16_up[i] + (size_t)s0 * e->wpack16_up_stem[i]; p.wpack16_stem = e->wpack16_up_stem[i];
+                p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
+                rc2 = srt_launch_dec_f16(p, e->stream);
+            }
+            if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_dec2(p, e->stream);
             if (rc2 < 0) return fail(-2, "decoder launch failed");
             if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
         }

@@ -36,6 +36,9 @@ struct SrtConvParams {
                           // up5:   [Cin][15][32] per stem, rows = px*16+co, 15 = (ky, dx) pairs (two x-parity classes per tile)
     size_t wpack2_stem;
     int CP2, stack;
+    // fp16-MFMA variant (srt_nn3.hip): [Cin/16][25][2][CP][8] IEEE halves (k-group of 8 channels innermost)
+    const uint16_t* wpack16; size_t wpack16_stem;
+    int nsplit;           // 1: activations rounded to fp16; 2: activations split hi+lo (two MFMAs per tap, ~fp32 products)
     float* outRaw;        // encoder: conv+bias (skip tensor); decoder: unused
     float* outAct;        // encoder: act(bn(v)); decoder: bn(act(v))
     size_t out_stem, out_tile;
@@ -61,6 +64,10 @@ int  srt_launch_enc2(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_dec2(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack_stemstack(const float* coeff_w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s);
 int  srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, hipStream_t s);
+// fp16-MFMA kernels (srt_nn3.hip): return 1 when the layer is not covered (caller uses the fp32 kernels)
+int  srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s);
 int  srt_set_sigmoid_table(const float* tbl1026);
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);
 

@@ -76,34 +76,6 @@ __device__ __forceinline__ void srt_dma_piece(const float* wp, size_t rowStride,
     }
 }
 
-// ------------------------------------------------------------------------------------------- XCD-aware block order
-// The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with a private 4 MiB L2.  With the plain
-// (spatial, M-block, instance) order every XCD sees the weight slabs of several (stem, M-block) pairs at once (13 MB for
-// up2) and streams them from MALL/HBM for every workgroup (ablation: +8 % when the weight/patch traffic is removed).
-// Here the launch is 1-D and XCD x walks the x-th CONTIGUOUS chunk of the (stem, M-block)-major order, so at any time an
-// XCD works on one weight slab (1.6-3.3 MB, L2 resident) and on neighbouring pixel tiles.  Speed only: any placement
-// gives the same result.  Returns the position in (stem, M-block)-major order.
-__device__ __forceinline__ int srt_xcd_order(int total)
-{
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int q = total >> 3, r = total & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-}
-struct SrtBlockCoord { int sp, mblk, stem, grp; };
-// order: w = (stem, mblk) slowest, then instance group, then spatial tile (fastest: neighbours share halo rows)
-__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp)
-{
-    const int pos = srt_xcd_order(nsp * nmb * nstem * ngrp);
-    SrtBlockCoord c;
-    c.sp = pos % nsp;
-    const int t = pos / nsp;
-    c.grp = t % ngrp;
-    const int w = t / ngrp;
-    c.mblk = w % nmb;
-    c.stem = w / nmb;
-    return c;
-}
-
 // ------------------------------------------------------------------------------------------- encoder v2
 template <int TW, int SW> struct Enc2Pad {
     static constexpr int base = TW + 4;                 // halves per parity plane of a staged row

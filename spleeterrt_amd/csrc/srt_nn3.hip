@@ -1,0 +1,402 @@
+// srt_nn3.hip — fp16-MFMA variant of the conv stack (BASELINE configs[4]: fp16 MFMA conv, fp32 STFT/iSTFT).
+//
+// Same tiling idea as srt_nn2.hip (parity-class gather decoder, parity-plane encoder, LDS-DMA weight ring), but the
+// contraction runs on v_mfma_f32_32x32x16_f16: k-group = 16 input channels of one tap, fp32 accumulate, fp32 epilogue.
+// Activations stay fp32 in HBM (the fp32 layers down1 / up6 / head and all epilogues are unchanged) and are converted
+// while they are staged into LDS, channel-innermost ([k-group of 8][row][col][8 halves]) so that one ds_read_b128 is
+// one B fragment.  Weights are pre-packed [Cin/16][25][2][CP][8] halves: one 1-KiB DMA piece = two (tap, k-group) rows.
+//   nsplit = 1: activations rounded to fp16 (tolerance class of BASELINE configs[4]: mask 2e-2)
+//   nsplit = 2: activations split x = hi + lo (both fp16), two MFMAs per tap.  With fp16-representable weights (the
+//               reference's shipped model IS an fp16 container, main.c:423-443) every product is exact in fp32, so the
+//               result differs from the fp32 path only by the 2^-22 truncation of x and the summation order.
+#include "srt_device.h"
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------- packing
+__global__ void srt_pack16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int CP, int dec)
+{
+    const size_t total = (size_t)(Cin / 16) * 25 * 2 * CP * 8;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e % 8, co = (e / 8) % CP, g = (e / (8 * (size_t)CP)) % 2, tap = (e / (16 * (size_t)CP)) % 25, cg = e / (400 * (size_t)CP);
+        const int ci = cg * 16 + g * 8 + q;
+        float v = 0.0f;
+        if (co < Cout) v = dec ? w[((size_t)ci * Cout + co) * 25 + tap] : w[((size_t)co * Cin + ci) * 25 + tap];
+        wp[e] = (_Float16)v;
+    }
+}
+int srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_pack16_kernel, dim3(1024), dim3(256), 0, s, w, (_Float16*)wp16, Cin, Cout, CP, dec);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+__device__ __forceinline__ void srt_dma16h(const _Float16* gsrc, _Float16* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// weight slab of one 16-channel group for BM = 32: 50 rows (tap, k-group) of 32 x 8 halves = 512 B; one piece = 2 rows
+__device__ __forceinline__ void srt_dma_slab16(const _Float16* wp, int CP, _Float16* lds, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int piece = wave + 4 * i;                      // wave-uniform, 25 pieces
+        if (piece < 25) {
+            const int row = 2 * piece + (lane >> 5);
+            srt_dma16h(wp + ((size_t)row * CP + (lane & 31)) * 8, lds + piece * 512);
+        }
+    }
+}
+__device__ __forceinline__ void srt_split(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// ------------------------------------------------------------------------------------------- decoder, fp16 MFMA
+template <int SW, int NSX, int NSY, int NI, int NSPLIT>
+__global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
+{
+    const SrtAct actp = srt_act_params(p.act, p.variant);
+    constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
+    static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
+    constexpr int PH = TH + 2, PC = TW + 8, RW4 = PC / 4;
+    constexpr int PLANE = NI * PH * PC * 8;                 // halves per k-group plane
+    constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
+    constexpr int WSLAB = 25 * 512;                         // halves per weight slab (25 KiB)
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
+    _Float16* s_in = s_mem;
+    _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (p.Cout + BM - 1) / BM, p.nstems, groups);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
+    const size_t cgStride = (size_t)50 * p.CP * 8;          // halves per 16-channel group
+
+    float4 pin[NLD][8];
+    auto load_patch = [&](int cg) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + i * 256, NIT - 1);
+            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
+            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
+                pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NIT) {
+                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
+                _Float16* d = s_in + gg * PLANE + ((il * PH + r) * PC + 4 * j) * 8;
+                h8 hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float x[4] = { pin[i][q].x, pin[i][q].y, pin[i][q].z, pin[i][q].w };
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        _Float16 a, b;
+                        srt_split(x[px], a, b);
+                        hi[px][q] = a; lo[px][q] = b;
+                    }
+                }
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    *reinterpret_cast<h8*>(d + px * 8) = hi[px];
+                    if (NSPLIT == 2) *reinterpret_cast<h8*>(d + 2 * PLANE + px * 8) = lo[px];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[4][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.0f;
+
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int a = sy * SH + l31 / SW, b = sx * SW + l31 % SW;
+        boff[nr] = g * PLANE + ((il * PH + a) * PC + b + 3) * 8;        // + ((1+dy)*PC + (1+dx))*8 -> column b+dx+4
+    }
+    const int aoff = (g * BM + l31) * 8;
+
+    const int nchunks = p.Cin / 16;
+    srt_dma_slab16(wp, p.CP, s_w, wave, lane);
+    load_patch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        store_patch();
+        __syncthreads();
+        const _Float16* sw = s_w + (ch & 1) * WSLAB;
+        if (ch + 1 < nchunks) {
+            srt_dma_slab16(wp + (size_t)(ch + 1) * cgStride, p.CP, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch(ch + 1);
+        }
+#pragma unroll
+        for (int sh = 0; sh < 9; ++sh) {                                  // shift-major: one B fragment set live at a time
+            const int dy = sh / 3 - 1, dx = sh % 3 - 1;
+            h8 bh[NR], bl[NR];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                bh[nr] = *reinterpret_cast<const h8*>(s_in + boff[nr] + ((1 + dy) * PC + (1 + dx)) * 8);
+                if (NSPLIT == 2) bl[nr] = *reinterpret_cast<const h8*>(s_in + 2 * PLANE + boff[nr] + ((1 + dy) * PC + (1 + dx)) * 8);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int py = (ky + 1) & 1;
+                if ((py + 1 - ky) / 2 != dy) continue;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int px = (kx + 1) & 1;
+                    if ((px + 1 - kx) / 2 != dx) continue;
+                    const h8 a = *reinterpret_cast<const h8*>(sw + (ky * 5 + kx) * 2 * BM * 8 + aoff);
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        acc[py * 2 + px][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh[nr], acc[py * 2 + px][nr], 0, 0, 0);
+                        if (NSPLIT == 2) acc[py * 2 + px][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl[nr], acc[py * 2 + px][nr], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const float* bias = p.bias + stem * p.coeff_stem;
+    const float* scale = p.bnScale + stem * p.coeff_stem;
+    const float* shift = p.bnShift + stem * p.coeff_stem;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float bi[16], sc[16], sf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * g, p.Cout - 1);
+        bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
+    }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int a = ty0 + sy * SH + l31 / SW, b = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+        const bool pix_ok = tile < p.ntiles && a < p.H && b < p.W;
+        const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)(2 * a) * Wo + 2 * b : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (pix_ok && m < p.Cout) {
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    float2 v;
+                    v.x = srt_dec_epilogue(acc[py * 2 + 0][nr][r], bi[r], sc[r], sf[r], actp);
+                    v.y = srt_dec_epilogue(acc[py * 2 + 1][nr][r], bi[r], sc[r], sf[r], actp);
+                    *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- encoder, fp16 MFMA
+template <int TW, int SW> struct Enc16Pad {
+    static constexpr int base = TW + 4;
+    static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
+};
+template <int SW, int NSX, int NSY, int NI, int NSPLIT>
+__global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
+{
+    const SrtAct actp = srt_act_params(p.act, p.variant);
+    constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
+    static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
+    constexpr int PH = 2 * TH + 3, RW4 = (2 * TW + 8) / 4, PWH = Enc16Pad<TW, SW>::value;
+    constexpr int ROWS = 2 * PWH, PLANE = NI * PH * ROWS * 8;
+    constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
+    constexpr int WSLAB = 25 * 512;
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
+    _Float16* s_in = s_mem;
+    _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
+    const int groups = (p.ntiles + NI - 1) / NI;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (p.Cout + BM - 1) / BM, p.nstems, groups);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    const size_t hw = (size_t)p.H * p.W;
+    const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
+    const size_t cgStride = (size_t)50 * p.CP * 8;
+
+    float4 pin[NLD][8];
+    auto load_patch = [&](int cg) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + i * 256, NIT - 1);
+            const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
+            const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
+            const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
+                pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            if (e < NIT) {
+                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
+                _Float16* d = s_in + gg * PLANE + ((il * PH + r) * ROWS + 2 * j) * 8;   // plane 0 halves 2j,2j+1; plane 1 at +PWH
+                h8 hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float x[4] = { pin[i][q].x, pin[i][q].y, pin[i][q].z, pin[i][q].w };
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        _Float16 a, b;
+                        srt_split(x[px], a, b);
+                        hi[px][q] = a; lo[px][q] = b;
+                    }
+                }
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const int off = ((px & 1) * PWH + (px >> 1)) * 8;                    // even columns -> plane 0, odd -> plane 1
+                    *reinterpret_cast<h8*>(d + off) = hi[px];
+                    if (NSPLIT == 2) *reinterpret_cast<h8*>(d + 2 * PLANE + off) = lo[px];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    int boff[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int oy = sy * SH + l31 / SW, ox = sx * SW + l31 % SW;
+        boff[nr] = g * PLANE + ((il * PH + 2 * oy) * ROWS + ox) * 8;
+    }
+    const int aoff = (g * BM + l31) * 8;
+
+    const int nchunks = p.Cin / 16;
+    srt_dma_slab16(wp, p.CP, s_w, wave, lane);
+    load_patch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        store_patch();
+        __syncthreads();
+        const _Float16* sw = s_w + (ch & 1) * WSLAB;
+        if (ch + 1 < nchunks) {
+            srt_dma_slab16(wp + (size_t)(ch + 1) * cgStride, p.CP, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch(ch + 1);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            const int koff = (ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)) * 8;
+            const h8 a = *reinterpret_cast<const h8*>(sw + tap * 2 * BM * 8 + aoff);
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const h8 bh = *reinterpret_cast<const h8*>(s_in + boff[nr] + koff);
+                acc[nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[nr], 0, 0, 0);
+                if (NSPLIT == 2) {
+                    const h8 bl = *reinterpret_cast<const h8*>(s_in + 2 * PLANE + boff[nr] + koff);
+                    acc[nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nr], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const bool hasBn = p.bnScale != nullptr;
+    const size_t ohw = (size_t)Ho * Wo;
+    const float* bias = p.bias + stem * p.coeff_stem;
+    float bi[16], sc[16], sf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * g, p.Cout - 1);
+        bi[r] = bias[m];
+        sc[r] = hasBn ? p.bnScale[stem * p.coeff_stem + m] : 0.0f;
+        sf[r] = hasBn ? p.bnShift[stem * p.coeff_stem + m] : 0.0f;
+    }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int s = wave * NR + nr;
+        const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
+        const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
+        const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
+        const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (pix_ok && m < p.Cout) {
+                const float v = acc[nr][r] + bi[r];
+                p.outRaw[obase + (size_t)m * ohw] = v;
+                if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], actp);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+template <int SW, int NSX, int NSY, int NI>
+static int launch_dec16(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
+    if (p.nsplit == 2) hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int SW, int NSX, int NSY, int NI>
+static int launch_enc16(const SrtConvParams& p, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
+    if (p.nsplit == 2) hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
+{
+    if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 32) return 1;       // down1 (Cin = 2) stays on the fp32 kernel
+    const int Wo = p.W / 2;
+    if (Wo >= 64) return launch_enc16<32, 2, 4, 1>(p, s);                    // 4 rows x 64 cols
+    if (Wo >= 32) return launch_enc16<32, 1, 8, 1>(p, s);                    // one 8x32 instance
+    return launch_enc16<16, 1, 2, 4>(p, s);                                  // 4 instances of 4x16
+}
+int srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s)
+{
+    if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 16 || p.CA % 16) return 1;   // up6 (Cout = 1) stays fp32
+    if (p.W >= 64) return launch_dec16<32, 2, 4, 1>(p, s);                   // 4 rows x 64 cols
+    if (p.W >= 32) return launch_dec16<32, 1, 8, 1>(p, s);                   // 8 rows x 32 cols (whole 8x32 instance for up2)
+    return launch_dec16<16, 1, 2, 4>(p, s);                                  // up1: 4 instances of 4x16
+}

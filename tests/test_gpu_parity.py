@@ -241,3 +241,28 @@ def test_rejects_bad_arguments():
     with pytest.raises(srt.EngineError):
         eng.stft(big, big)                                    # more tiles than max_tiles
     eng.close()
+
+
+@pytest.mark.parametrize("prec,mask_tol", [("f16", 2e-2), ("f16x2", MASK_TOL_EXACT)])
+@pytest.mark.parametrize("T,F", [(64, 512), (128, 1024)])
+def test_fp16_mfma_variants(oracle, coeffs, prec, mask_tol, T, F):
+    """BASELINE configs[4]: fp16 MFMA conv (fp32 accumulate, fp32 STFT/iSTFT) against the CPU fp32 oracle.
+    f16   : activations rounded to fp16         -> mask max-abs <= 2e-2
+    f16x2 : activations split hi+lo, weights are fp16-representable -> products exact, held to the fp32 tolerance."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = (1, 0)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=2,
+                  precision=srt.PREC_F16 if prec == "f16" else srt.PREC_F16X2)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, 2, T, F, seed=77)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    worst = 0.0
+    for s in range(2):
+        for t in range(2):
+            y = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST)
+            worst = max(worst, float(np.abs(masks[s, t] - y).max()))
+    print("fp16 variant %s %dx%d worst mask err %.3g" % (prec, T, F, worst))
+    assert worst <= mask_tol
+    eng.close()
