@@ -389,9 +389,19 @@ int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
 {
     if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 32) return 1;       // down1 (Cin = 2) stays on the fp32 kernel
     const int Wo = p.W / 2;
-    if (Wo >= 64) return launch_enc16<32, 2, 4, 1>(p, s);                    // 4 rows x 64 cols
-    if (Wo >= 32) return launch_enc16<32, 1, 8, 1>(p, s);                    // one 8x32 instance
-    return launch_enc16<16, 1, 2, 4>(p, s);                                  // 4 instances of 4x16
+    const char* tv = getenv("SRT_TUNE16");
+    const int v = tv ? atoi(tv) : 0;
+    if (Wo >= 64) {
+        if (v == 1) return launch_enc16<32, 2, 4, 1>(p, s);                  // 4 rows x 64 cols: 99 KB LDS, 1 workgroup / CU
+        if (v == 2) return launch_enc16<32, 2, 2, 1>(p, s);                  // 2 rows x 64 cols
+        return launch_enc16<32, 1, 4, 1>(p, s);                              // 4 rows x 32 cols: 76 KB LDS, 2 workgroups / CU
+    }
+    if (Wo >= 32) {
+        if (v == 1) return launch_enc16<32, 1, 8, 1>(p, s);                  // one 8x32 instance
+        return launch_enc16<32, 1, 4, 1>(p, s);
+    }
+    if (v == 1) return launch_enc16<16, 1, 2, 4>(p, s);                      // 4 instances of 4x16
+    return launch_enc16<16, 1, 2, 2>(p, s);                                  // 2 instances of 4x16
 }
 int srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s)
 {
