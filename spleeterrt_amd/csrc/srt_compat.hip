@@ -16,6 +16,13 @@ static void die(const char* where)
 }
 #define HIPDIE(x, where) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "libspleeterrt_amd: %s: %s\n", where, hipGetErrorString(_e)); abort(); } } while (0)
 
+static int env_precision()       // SPLEETERRT_PRECISION = f32 (default) | f16 | f16x2, see SRT_PREC_* in spleeterrt_amd.h
+{
+    const char* v = getenv("SPLEETERRT_PRECISION");
+    if (v && !strcmp(v, "f16")) return SRT_PREC_F16;
+    if (v && !strcmp(v, "f16x2")) return SRT_PREC_F16X2;
+    return SRT_PREC_F32;
+}
 static int env_variant()
 {
     const char* v = getenv("SPLEETERRT_VARIANT");
@@ -38,7 +45,7 @@ void initSpleeter(struct _spleeter* nn, size_t width, size_t height, int stemMod
     const int F = (int)(width & 0xffffffffu), T = (int)(height & 0xffffffffu);
     srt_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.F = F; cfg.T = T; cfg.n_stems = 1; cfg.stem_mode[0] = stemMode; cfg.oob_weight[0] = 1.0f;
-    cfg.variant = env_variant(); cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA;
+    cfg.variant = env_variant(); cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA; cfg.precision = env_precision();
     if (srtCreate(&cfg, nullptr, &nn->eng)) die("initSpleeter");
     if (srtSetCoeffHost(nn->eng, 0, coeff)) die("initSpleeter(weights)");
     nn->hw2 = 2 * (size_t)F * T;
