@@ -44,7 +44,7 @@ LAYER_SYMBOL = {
     "down5": "srt_enc_mfma2<64, 2, 32, 1, 8, 1, 4, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false>",
     "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0>",
     "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0>",
-    "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 32, 32>", "up7": "srt_head_kernel",
+    "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel",
 }
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc.json")     # written by scripts/summarize_profiles.py from separate --pmc passes
 

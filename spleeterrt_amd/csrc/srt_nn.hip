@@ -15,6 +15,7 @@
 //   * global->LDS staging is register-prefetched one K-chunk ahead so HBM/L2 latency hides under the MFMAs.
 // The naive kernels are a bit-simple cross-check path (SRT_IMPL_NAIVE) and serve layers not yet on MFMA.
 #include "srt_device.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------- activations
 __device__ float g_sigmoid_tbl[1026];
@@ -651,9 +652,15 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
-        constexpr int TH = 8, TW = 32;
-        dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), 1, p.nstems * p.ntiles);
-        hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), grid, dim3(256), 0, s, p);
+        const char* tv = getenv("SRT_TUNE_UP6");
+        const int v = tv ? atoi(tv) : 0;
+#define UP6_LAUNCH(TH, TW) hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), 1, p.nstems * p.ntiles), dim3(256), 0, s, p)
+        if (v == 1) UP6_LAUNCH(16, 32);
+        else if (v == 5) UP6_LAUNCH(8, 32);
+        else if (v == 3) UP6_LAUNCH(4, 64);
+        else if (v == 4) UP6_LAUNCH(4, 128);
+        else UP6_LAUNCH(8, 64);                       // measured: 8x64 0.76 ms, 4x128 0.81, 4x64 0.85, 16x32 0.96, 8x32 0.98
+#undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     if (p.Cout < 16) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
