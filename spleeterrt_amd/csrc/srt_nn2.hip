@@ -585,7 +585,15 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     const int Wo = p.W / 2;
     if (p.Cin == 2) {                                                                    // down1, stem-stacked M
         if (!p.wpack2 || p.stack < 1) return 1;
-        if (p.stack * p.Cout > 32) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
+        if (p.stack * p.Cout > 32) {
+            switch (tune("down1")) {
+            case 1: return launch_enc2_cfg<64, 2, 32, 4, 2, 1, 2, true>(p, s);          // 2 rows x 128 cols
+            case 2: return launch_enc2_cfg<64, 1, 32, 2, 4, 1, 2, true>(p, s);          // MR = 2
+            case 3: return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 2, true>(p, s);          // 8 rows x 32 cols
+            case 4: return launch_enc2_cfg<64, 2, 32, 2, 8, 1, 2, true>(p, s);          // 8 rows x 64 cols, NR = 8
+            default: return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
+            }
+        }
         return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
     }
     if (p.Cout <= 32) {                                                                  // down2 (an 8x64 tile / NR = 4 measured 4 % slower)
