@@ -18,4 +18,6 @@ for _ in range(K): eng.separate(L, R, out)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 eng.set_timing(True); eng.separate(L, R, out); tim = eng.get_timing()
 print("C2 latency (2 stems, 1 tile of 256x1024, %s): %.3f ms per tile = %.0f x real-time" % (sys.argv[1] if len(sys.argv) > 1 else "f32", dt * 1e3, 256 * 1024 / 44100 / dt))
-print({k: round(v, 3) for k, v in tim})
+agg = {}
+[agg.__setitem__(k, agg.get(k, 0.0) + v) for k, v in tim]
+print({k: round(v, 3) for k, v in agg.items()})

@@ -21,6 +21,7 @@ __device__ __forceinline__ float srt_act(float x, int kind, int variant)
 // of a chain of scalar branches (the branchy form was 88 % of the decoder kernel's instructions).
 //   x >= 0 ? x : lin*x + ue*((x < thr) ? -1 : exp(x) - 1)      leaky: (0.2, 0, -inf)  relu: (0, 0, -inf)  elu: (0, 1, -15 | -inf)
 struct SrtAct { float lin, ue, thr; };
+__device__ __forceinline__ int srt_act_kind(const SrtConvParams& p, int stem) { return ((p.elu_mask >> stem) & 1u) ? SRT_ACT_ELU : p.act; }
 __device__ __forceinline__ SrtAct srt_act_params(int kind, int variant)
 {
     SrtAct a;

@@ -232,11 +232,12 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
     // so stems with different modes are launched as separate groups.
     const size_t HW = (size_t)T * F;
     e->last_ntiles = ntiles;
-    for (int s0 = 0; s0 < S;) {
-        int s1 = s0 + 1;
-        while (s1 < S && (e->cfg.stem_mode[s1] != 0) == (e->cfg.stem_mode[s0] != 0)) ++s1;
-        const int ns = s1 - s0;
-        const int actE = e->cfg.stem_mode[s0] ? SRT_ACT_ELU : SRT_ACT_LEAKY, actD = e->cfg.stem_mode[s0] ? SRT_ACT_ELU : SRT_ACT_RELU;
+    {
+        // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
+        const int s0 = 0, ns = S;
+        unsigned elu_mask = 0;
+        for (int s = 0; s < S; ++s) if (e->cfg.stem_mode[s]) elu_mask |= 1u << s;
+        const int actE = SRT_ACT_LEAKY, actD = SRT_ACT_RELU;
         const float* cbase = e->coeff_all + (size_t)s0 * SRT_COEFF_STRIDE;
         char nm[32];
         for (int i = 0; i < 6; ++i) {                                           // encoder (spleeter.c:182-238)
@@ -253,7 +254,7 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             p.outRaw = e->raw[i] + (size_t)s0 * ntiles * e->raw_tile[i];
             p.outAct = i < 5 ? e->act[i] + (size_t)s0 * ntiles * e->act_tile[i] : nullptr;
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
-            p.act = actE; p.variant = e->cfg.variant;
+            p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
                 p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
                 if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
@@ -288,7 +289,7 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             p.outRaw = nullptr;
             p.outAct = e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
             p.out_stem = (size_t)ntiles * e->up_tile[i]; p.out_tile = e->up_tile[i];
-            p.act = actD; p.variant = e->cfg.variant;
+            p.act = actD; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (i == 4) { p.wpack2 = e->wpack2_u5 + (size_t)s0 * 64 * 15 * 32; p.wpack2_stem = 64 * 15 * 32; p.CP2 = 32; }
             snprintf(nm, sizeof nm, "up%d", i + 1);
             TimerScope ts(e, nm);
@@ -312,7 +313,6 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
             TimerScope ts(e, "up7");
             if (srt_launch_head(h, e->stream)) return fail(-2, "head launch failed");
         }
-        s0 = s1;
     }
     return 0;
 }

@@ -42,7 +42,9 @@ struct SrtConvParams {
     float* outRaw;        // encoder: conv+bias (skip tensor); decoder: unused
     float* outAct;        // encoder: act(bn(v)); decoder: bn(act(v))
     size_t out_stem, out_tile;
-    int act, variant;
+    int act;              // activation kind of the stems whose elu_mask bit is clear (encoder: LeakyReLU, decoder: ReLU)
+    unsigned elu_mask;    // bit s set: stem s of this launch uses ELU (stemMode != 0, spleeter.c:130-139)
+    int variant;
 };
 
 struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sigmoid  (spleeter.c:156,295-300)

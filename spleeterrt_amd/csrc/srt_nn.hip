@@ -69,7 +69,7 @@ __global__ void srt_enc_naive(const SrtConvParams p)
         const float v = acc + p.bias[cs + co];
         const size_t o = stem * p.out_stem + tile * p.out_tile + e;
         p.outRaw[o] = v;
-        if (p.bnScale) p.outAct[o] = srt_enc_epilogue(v, p.bnScale[cs + co], p.bnShift[cs + co], p.act, p.variant);
+        if (p.bnScale) p.outAct[o] = srt_enc_epilogue(v, p.bnScale[cs + co], p.bnShift[cs + co], srt_act_kind(p, stem), p.variant);
     }
 }
 
@@ -95,7 +95,7 @@ __global__ void srt_dec_naive(const SrtConvParams p)
             }
         }
         p.outAct[stem * p.out_stem + tile * p.out_tile + e] =
-            srt_dec_epilogue(acc, p.bias[stem * p.coeff_stem + co], p.bnScale[stem * p.coeff_stem + co], p.bnShift[stem * p.coeff_stem + co], p.act, p.variant);
+            srt_dec_epilogue(acc, p.bias[stem * p.coeff_stem + co], p.bnScale[stem * p.coeff_stem + co], p.bnShift[stem * p.coeff_stem + co], srt_act_kind(p, stem), p.variant);
     }
 }
 
@@ -228,7 +228,6 @@ template <int TW, int SW> struct EncPad {
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -250,6 +249,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
     const int m0 = blockIdx.y * BM;
     const int groups = (p.ntiles + NI - 1) / NI;
     const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* wp = p.wpack + stem * p.wpack_stem;
 
@@ -377,7 +377,6 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -396,6 +395,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
     const int m0 = blockIdx.y * BM;
     const int groups = (p.ntiles + NI - 1) / NI;
     const int stem = blockIdx.z / groups, tile0 = (blockIdx.z % groups) * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* wp = p.wpack + stem * p.wpack_stem;
 
@@ -536,13 +536,13 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 template <int TH, int TW, int CIN>
 __global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
     __shared__ float s_col[25 * NPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tilesX = (p.W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % tilesX) * TW, ty0 = (blockIdx.x / tilesX) * TH;
     const int stem = blockIdx.z / p.ntiles, tile = blockIdx.z % p.ntiles;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* w = p.wraw + stem * p.coeff_stem;               // [Cin][1][25]
     float a[CIN / 2];

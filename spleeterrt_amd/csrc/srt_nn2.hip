@@ -86,7 +86,6 @@ template <int TW, int SW> struct Enc2Pad {
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -112,6 +111,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const int CPW = STEMSTACK ? p.CP2 : p.CP;
     const float* wp = (STEMSTACK ? p.wpack2 : p.wpack + stem * p.wpack_stem) + m0;
@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     for (int mr = 0; mr < MR; ++mr) {
         float bi[16], sc[16], sf[16];
         size_t ob[16];
+        unsigned elu[16];                      // stem-stacked rows: the activation kind follows the row's stem
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1);
@@ -208,6 +209,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             sc[r] = hasBn ? p.bnScale[ci] : 0.0f;
             sf[r] = hasBn ? p.bnShift[ci] : 0.0f;
             ob[r] = st * p.out_stem + (size_t)co * ohw;
+            if (STEMSTACK) elu[r] = (p.elu_mask >> st) & 1u;
         }
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                 if (pix_ok && m < mlimit) {
                     const float v = acc[mr][nr][r] + bi[r];
                     p.outRaw[ob[r] + pbase] = v;
-                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], actp);
+                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], STEMSTACK ? srt_act_params(elu[r] ? SRT_ACT_ELU : p.act, p.variant) : actp);
                 }
             }
         }
@@ -234,7 +236,6 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
     static_assert(SH * SW == 32 && WM * WN == 4 && MR * 32 * WM == BM && NR * WN == NS, "bad tile");
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const int CPW = CLASSSTACK ? 32 : p.CP;
     const float* wp = (CLASSSTACK ? p.wpack2 + stem * p.wpack2_stem : p.wpack + stem * p.wpack_stem) + m0;
@@ -414,7 +416,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NSX, int NSY, int KC>                      // tile = NSY rows x (NSX*16) columns of input-resolution pixels
 __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int TW = NSX * 16, TH = NSY, NS = NSX * NSY, NR = NS / 4;
     static_assert(NS % 4 == 0 && KC == 4, "tile");
     constexpr int PH = TH + 2, RW4 = (TW + 8) / 4, ROWS = TW + 8, CHS = PH * ROWS;
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
     const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, 1, p.nstems, p.ntiles);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int stem = bc.stem, tile = bc.grp;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* wp = p.wpack + stem * p.wpack_stem;                        // [Cin][25][CP]
 

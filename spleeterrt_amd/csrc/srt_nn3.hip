@@ -60,7 +60,6 @@ __device__ __forceinline__ void srt_split(float x, _Float16& hi, _Float16& lo)
 template <int SW, int NSX, int NSY, int NI, int NSPLIT>
 __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
     static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
     constexpr int PH = TH + 2, PC = TW + 8, RW4 = PC / 4;
@@ -77,6 +76,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
     const int groups = (p.ntiles + NI - 1) / NI;
     const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (p.Cout + BM - 1) / BM, p.nstems, groups);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;          // halves per 16-channel group
@@ -224,7 +224,6 @@ template <int TW, int SW> struct Enc16Pad {
 template <int SW, int NSX, int NSY, int NI, int NSPLIT>
 __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 {
-    const SrtAct actp = srt_act_params(p.act, p.variant);
     constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
     static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
     constexpr int PH = 2 * TH + 3, RW4 = (2 * TW + 8) / 4, PWH = Enc16Pad<TW, SW>::value;
@@ -242,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     const int groups = (p.ntiles + NI - 1) / NI;
     const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (p.Cout + BM - 1) / BM, p.nstems, groups);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;
