@@ -65,17 +65,6 @@ __device__ __forceinline__ void srt_dma_slab(const float* wp, size_t rowStride, 
 }
 
 
-// one 1-KiB piece of a slab (piece index wave-uniform); used to spread the DMA issue between the MFMAs of a chunk
-template <int NROWS, int BM>
-__device__ __forceinline__ void srt_dma_piece(const float* wp, size_t rowStride, float* lds, int piece, int lane)
-{
-    constexpr int RPI = 256 / BM, NPIECE = (NROWS + RPI - 1) / RPI;
-    if (piece < NPIECE) {
-        const int row = min(piece * RPI + lane / (BM / 4), NROWS - 1);
-        srt_dma16(wp + (size_t)row * rowStride + (lane % (BM / 4)) * 4, lds + piece * 256);
-    }
-}
-
 // ------------------------------------------------------------------------------------------- encoder v2
 template <int TW, int SW> struct Enc2Pad {
     static constexpr int base = TW + 4;                 // halves per parity plane of a staged row
