@@ -72,7 +72,7 @@ template <int TW, int SW> struct Enc2Pad {
     static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
 };
 
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK>
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
@@ -105,27 +105,35 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     const int CPW = STEMSTACK ? p.CP2 : p.CP;
     const float* wp = (STEMSTACK ? p.wpack2 : p.wpack + stem * p.wpack_stem) + m0;
 
-    float4 pin[NLD];
-    auto load_patch_elem = [&](int c0, int i) {
-        const int e = min(tid + i * 256, NF4 - 1);
-        const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-        const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
-        const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-        const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
-        const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
-        pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto load_patch = [&](int c0) {
+    // Per-thread staging geometry is chunk independent (only the channel base moves), so the global offset, the LDS
+    // offset and the validity of each of this thread's NLD float4 elements are computed ONCE: the per-chunk staging is
+    // then a load, a select and two LDS stores per element (ablation: the index math was most of the 12 % this stage cost).
+    ptrdiff_t goff[NLD];
+    int loff[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) load_patch_elem(c0, i);
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * 256, ec = min(e, NF4 - 1);
+        const int j = ec % RW4, ru = ec / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+        const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
+        const bool ok = e < NF4 && tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        goff[i] = ok ? (ptrdiff_t)il * (ptrdiff_t)p.srcA_tile + (ptrdiff_t)c * (ptrdiff_t)hw + (ptrdiff_t)gy * p.W + gx : -1;
+        loff[i] = e < NF4 ? c * CHS + il * INS + r * ROWS + 2 * j : -1;
+    }
+    const float* srcBase = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;       // encoder layers read one source (CA == Cin)
+    float4 pin[NLD];
+    auto load_patch = [&](int c0) {
+        const float* base = srcBase + (size_t)c0 * hw;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (goff[i] >= 0 ? goff[i] : 0));
+            pin[i] = goff[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            if (e < NF4) {
-                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-                float* d = s_in + c * CHS + il * INS + r * ROWS + 2 * j;
+            if (loff[i] >= 0) {
+                float* d = s_in + loff[i];
                 *reinterpret_cast<float2*>(d) = make_float2(pin[i].x, pin[i].z);            // even columns -> plane 0
                 *reinterpret_cast<float2*>(d + PWH) = make_float2(pin[i].y, pin[i].w);      // odd columns  -> plane 1
             }
@@ -154,12 +162,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
     load_patch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_patch();
+        if ((ABL != 1 && ABL != 4) || ch == 0) store_patch();
         __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
         const float* sw = s_w + (ch & 1) * WSLAB;
-        if (ch + 1 < nchunks) {       // issued up front; spreading the pieces between the MFMAs measured no gain
-            srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
-            load_patch((ch + 1) * KC);
+        if (ch + 1 < nchunks && ABL != 1) {       // issued up front; spreading the pieces between the MFMAs measured no gain
+            if (ABL != 5) srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            if (ABL != 4) load_patch((ch + 1) * KC);
         }
 #pragma unroll
         for (int cp = 0; cp < KC / 2; ++cp) {
@@ -168,9 +176,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                 const int ky = tap / 5, kx = tap % 5;
                 float a[MR], b[NR];
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[mr] = sw[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
+                for (int mr = 0; mr < MR; ++mr) a[mr] = ABL == 3 ? (float)(tap + cp) : sw[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) b[nr] = s_in[boff[nr] + 2 * cp * CHS + ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)];
+                for (int nr = 0; nr < NR; ++nr) b[nr] = ABL == 3 ? (float)(nr + ch + tap) : s_in[boff[nr] + 2 * cp * CHS + ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -181,6 +189,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         __syncthreads();                                   // everyone is done with s_in and slab (ch&1)
     }
 
+    if (ABL == 7) return;                                  // ablation: no epilogue
     const bool hasBn = p.bnScale != nullptr;
     const size_t ohw = (size_t)Ho * Wo;
     const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
@@ -598,7 +607,20 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
         default: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
         }
     }
-    if (Wo >= 64) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);            // down3 / down4 class
+    if (Wo >= 64) {                                                                      // down3 / down4 class
+        const int abl = tune("eabl");                                                    // ablation builds (wrong results, timing only)
+        if (abl) {
+            constexpr int TW = 64, TH = 4;
+            dim3 grid(((Wo + TW - 1) / TW) * ((p.H / 2 + TH - 1) / TH) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
+            if (abl == 1) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 1>), grid, dim3(256), 0, s, p);
+            if (abl == 3) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 3>), grid, dim3(256), 0, s, p);
+            if (abl == 4) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
+            if (abl == 5) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
+            if (abl == 7) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 7>), grid, dim3(256), 0, s, p);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);
+    }
     if (Wo >= 32) return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 4, false>(p, s);            // down5 class
     return launch_enc2_cfg<64, 2, 16, 1, 2, 4, 4, false>(p, s);                          // down6 class
 }
