@@ -15,6 +15,7 @@
  *   srtStft                     stft + the magnitude loop of processMT               Executable/stftFix.c:363-495, main.c:462-471
  *   srtIstft                    the mask loop of processMT + istft                   Executable/main.c:473-494, stftFix.c:496-579
  *   srtSeparate                 main()'s stft -> processMT -> istft sequence         Executable/main.c:776-785
+ *   srtSeparateCli              main()'s two- and three-output flows incl. residuals  Executable/main.c:776-798, 845-928
  * The drop-in, host-pointer forms with the reference's exact signatures are in spleeter.h / stftFix.h.
  */
 #ifndef SPLEETERRT_AMD_H
@@ -47,6 +48,7 @@ typedef struct srt_config {
     int   max_tiles;                /* capacity: tiles per batch */
     int   impl;                     /* SRT_IMPL_* */
     int   precision;                /* SRT_PREC_*: arithmetic of the conv contraction (accumulation and everything else is fp32) */
+    int   ratio_mask;               /* 0 (reference behaviour: raw sigmoid masks) | 1: srtSeparate* normalises m_s^2 / sum_j m_j^2 across stems (README.MD:82-85) */
 } srt_config;
 
 SRT_API int  srtCreate(const srt_config *cfg, void *stream, srt_engine **out);
@@ -61,6 +63,11 @@ SRT_API int  srtSetCoeffFp16Host(srt_engine *e, int stem, const uint16_t *h_half
 
 /* d_mag: [ntiles][2][T][F] magnitudes; d_masks: [n_stems][ntiles][2][T][F] */
 SRT_API int  srtForward(srt_engine *e, const float *d_mag, int ntiles, float *d_masks);
+
+/* the same for sub-networks [stem0, stem0+nstems) only; d_masks keeps the all-stem layout (stem s at s*ntiles*2*T*F) */
+SRT_API int  srtForwardStems(srt_engine *e, const float *d_mag, int ntiles, float *d_masks, int stem0, int nstems);
+/* in place on d_masks [n_stems][ntiles][2][T][F]: m_s <- (m_s^2 + 1e-10/S) / (sum_j m_j^2 + 1e-10)  (official-Spleeter ratio mask; not in the reference) */
+SRT_API int  srtRatioMask(srt_engine *e, float *d_masks, int ntiles);
 
 /* geometry helpers for an n-sample stereo signal (n >= 4096) */
 SRT_API size_t srtStftRows(size_t n);            /* ceil(n/1024): rows the reference allocates          stftFix.c:367 */
@@ -78,6 +85,12 @@ SRT_API int  srtSeparate(srt_engine *e, const float *d_L, const float *d_R, size
  * sample i*1024, zero padded past n) and emit `rows` >= frames rows (the extra rows are zero, as the reference's calloc). */
 SRT_API int  srtStftEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_spec, float *d_mag);
 SRT_API int  srtSeparateEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_out);
+
+/* The offline CLI's flows (Executable/main.c:776-798 for stems == 2, :845-928 for stems == 3), everything in HBM.
+ * Sub-network 0 = the CLI's net[0] (drum, stem_mode 1), sub-network 1 = net[1] (vocal, stem_mode 0)  (main.c:759-760).
+ * d_out: [stems][2][srtIstftLength(srtStftRows(n))] in the CLI's output order: Vocal, Accompaniment | Drum, Vocal, Accompaniment. */
+SRT_API int  srtSeparateCli(srt_engine *e, const float *d_L, const float *d_R, size_t n, int stems, float *d_out);
+SRT_API int  srtSeparateCliHost(srt_engine *e, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);  /* host buffers, synchronous */
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */

@@ -212,6 +212,40 @@ def process_spectrogram(coeff, re, im, F, T, stem_mode, variant=VARIANT_EXE, una
     lib().orc_process_spectrogram(np.ascontiguousarray(coeff), F, T, stem_mode, variant, re.shape[1], re[0], im[0], re[1], im[1], unaffected)
 
 
+def cli_separate(coeff_net0, coeff_net1, L, R, F, T, stems, variant=VARIANT_EXE, unaffected=0.1):
+    """The offline CLI's two- and three-output flows restated over the oracle's own stft / processMT / istft
+    (Executable/main.c:776-798 and :845-928).  net0 = coeffProvPtr2 (drum, mode 1), net1 = coeffProvPtr1 (vocal, mode 0)
+    (main.c:759-760).  Returns [stems][2][rows*1024+3072] in file order: (Vocal, Accompaniment) or (Drum, Vocal, Accompaniment).
+    The reference's main() cannot be built here (its embedded model.c is absent), so this flow is pinned by reading only;
+    every stage it calls is pinned on its own against oracle/_ref."""
+    L = np.ascontiguousarray(L, np.float32)
+    R = np.ascontiguousarray(R, np.float32)
+    n = L.size
+    re, im = stft(L, R)
+    if stems == 2:
+        process_spectrogram(coeff_net1, re, im, F, T, 0, variant, unaffected)                    # main.c:779
+        vocal = istft(re, im)
+        acc = -vocal.copy()
+        acc[0, :n] = L - vocal[0, :n]                                                            # main.c:794-798
+        acc[1, :n] = R - vocal[1, :n]
+        return np.stack([vocal, acc])
+    ore, oim = re.copy(), im.copy()                                                              # main.c:849-856
+    process_spectrogram(coeff_net0, re, im, F, T, 1, variant, unaffected)                        # main.c:858
+    ore -= re                                                                                    # main.c:860-866
+    oim -= im
+    drum = istft(re, im)
+    accvocal = istft(ore, oim)                                                                   # main.c:881
+    process_spectrogram(coeff_net1, ore, oim, F, T, 0, variant, unaffected)                      # main.c:911
+    vocal = istft(ore, oim)
+    return np.stack([drum, vocal, accvocal - vocal])                                             # main.c:924-928
+
+
+def ratio_mask(masks, eps=1e-10):
+    """Official-Spleeter cross-stem normalisation (absent from the reference, README.MD:82-85): masks [S, ...]."""
+    sq = masks.astype(np.float32) ** 2
+    return ((sq + np.float32(eps / masks.shape[0])) / (sq.sum(axis=0, dtype=np.float32) + np.float32(eps))).astype(np.float32)
+
+
 # ---------------------------------------------------------------- real reference (oracle/_ref)
 def ref_path(flavour="exe"):
     name = {"exe": "libspleeter_ref.so", "avx2": "libspleeter_ref_avx2.so", "vst": "libspleeter_ref_vst.so",

@@ -18,7 +18,8 @@ class EngineError(RuntimeError):
 
 class _Config(C.Structure):
     _fields_ = [("F", C.c_int), ("T", C.c_int), ("n_stems", C.c_int), ("stem_mode", C.c_int * MAX_STEMS),
-                ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int), ("precision", C.c_int)]
+                ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int), ("precision", C.c_int),
+                ("ratio_mask", C.c_int)]
 
 
 _lib = None
@@ -43,6 +44,10 @@ def load_library():
     L.srtSetCoeffDevice.argtypes = [vp, C.c_int, vp]
     L.srtSetCoeffFp16Host.argtypes = [vp, C.c_int, vp]
     L.srtForward.argtypes = [vp, f32p, C.c_int, f32p]
+    L.srtForwardStems.argtypes = [vp, f32p, C.c_int, f32p, C.c_int, C.c_int]
+    L.srtRatioMask.argtypes = [vp, f32p, C.c_int]
+    L.srtSeparateCli.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_int, f32p]
+    L.srtSeparateCliHost.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
     for fn in (L.srtStftRows, L.srtStftFrames, L.srtIstftLength):
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_size_t]
@@ -66,7 +71,7 @@ class Engine:
     """One engine per (device, stream): nstems sub-networks evaluated over batches of T x F spectrogram tiles."""
 
     def __init__(self, F=1024, T=256, stem_modes=(1, 1, 1, 1), oob_weights=None, variant=VARIANT_EXE, max_tiles=1,
-                 impl=IMPL_MFMA, device=None, precision=PREC_F32):
+                 impl=IMPL_MFMA, device=None, precision=PREC_F32, ratio_mask=False):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: spleeterrt_amd has no CPU path")
@@ -78,6 +83,7 @@ class Engine:
         cfg = _Config()
         cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.impl = F, T, self.S, variant, max_tiles, impl
         cfg.precision = precision
+        cfg.ratio_mask = int(bool(ratio_mask))
         for i, m in enumerate(stem_modes):
             cfg.stem_mode[i] = int(m)
             cfg.oob_weight[i] = 0.1 if oob_weights is None else float(oob_weights[i])
@@ -132,6 +138,17 @@ class Engine:
         self._chk(self.L.srtForward(self.h, _ptr(mag), nt, _ptr(masks)))
         return masks
 
+    def forward_stems(self, mag, masks, stem0, nstems):
+        """sub-networks [stem0, stem0+nstems) only; masks keeps the all-stem shape [S,ntiles,2,T,F]"""
+        self._chk(self.L.srtForwardStems(self.h, _ptr(mag.contiguous()), mag.shape[0], _ptr(masks), stem0, nstems))
+        return masks
+
+    def ratio_mask(self, masks):
+        """in place: m_s <- (m_s^2 + eps/S) / (sum_j m_j^2 + eps) across the stem axis"""
+        assert masks.is_contiguous() and masks.shape[0] == self.S
+        self._chk(self.L.srtRatioMask(self.h, _ptr(masks), masks.shape[1]))
+        return masks
+
     def stft(self, L, R, want_mag=True):
         """planar PCM -> (spec [2,rows,2052,2], mag [ntiles,2,T,F] or None)"""
         t = self.torch
@@ -159,6 +176,14 @@ class Engine:
         if out is None:
             out = t.empty((self.S, 2, self.L.srtIstftLength(rows)), device=self.device, dtype=t.float32)
         self._chk(self.L.srtSeparate(self.h, _ptr(L), _ptr(R), n, _ptr(out)))
+        return out
+
+    def separate_cli(self, L, R, stems):
+        """the offline CLI's flow (main.c:776-798 / 845-928): -> [stems,2,len] = (Vocal, Accompaniment) or (Drum, Vocal, Accompaniment)"""
+        t = self.torch
+        n = L.numel()
+        out = t.empty((stems, 2, self.L.srtIstftLength(self.L.srtStftRows(n))), device=self.device, dtype=t.float32)
+        self._chk(self.L.srtSeparateCli(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, stems, _ptr(out)))
         return out
 
     def separate_ex(self, L, R, frames, rows, out=None):

@@ -297,6 +297,92 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- residual chain / ratio mask
+// Complex-domain residual of the three-output CLI flow (main.c:845-866): the first network's masked spectrum is subtracted
+// from the original, and the second network sees the magnitude of what is left.  Same two roundings as the reference
+// (product, then difference: no fused multiply-add).  One workgroup = one spectrogram row of one channel.  HBM bound:
+// 16.4 KB read + 16.4 KB written + 2 x 4 F bytes per row.
+__global__ void __launch_bounds__(256) srt_residual_kernel(const SrtResidualParams p)
+{
+    const int row = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int tile = row / p.T, t = row % p.T;
+    const float2* src = p.spec + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
+    float2* dst = p.res + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
+    const size_t mo = ((size_t)(tile * 2 + ch) * p.T + t) * p.F;
+    const float* m = p.mask + mo;
+    float* mag = p.mag ? p.mag + mo : nullptr;
+    for (int k = tid; k < SRT_SPEC_LD; k += 256) {
+        float2 r = f2(0.f, 0.f);
+        if (k <= 2048) {
+            const float2 v = src[k];
+            const float g = k < p.F ? m[k] : p.oob;
+            r.x = __fsub_rn(v.x, __fmul_rn(v.x, g));
+            r.y = __fsub_rn(v.y, __fmul_rn(v.y, g));
+            if (mag && k < p.F) mag[k] = hypotf(r.x, r.y) * 4096.0f;
+        }
+        dst[k] = r;
+    }
+}
+
+int srt_launch_residual(const SrtResidualParams& p, hipStream_t s)
+{
+    if (p.rows <= 0) return 0;
+    hipLaunchKernelGGL(srt_residual_kernel, dim3(p.rows, 2), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+__global__ void __launch_bounds__(256) srt_time_residual_kernel(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    const float* a = blockIdx.y ? aR : aL;
+    const size_t o = (size_t)blockIdx.y * nb + i;
+    out[o] = (i < na ? a[i] : 0.0f) - b[o];
+}
+
+int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s)
+{
+    if (!nb) return 0;
+    hipLaunchKernelGGL(srt_time_residual_kernel, dim3((unsigned)((nb + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Cross-stem ratio mask (what official Spleeter applies and the reference deliberately leaves out, README.MD:82-85):
+// every stem's mask is squared and normalised by the sum over stems at the same (tile, channel, frame, bin).
+__global__ void __launch_bounds__(256) srt_ratio_mask_kernel(float* masks, int nstems, size_t count)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= count) return;                                        // count is a multiple of 4 (F % 64 == 0)
+    float4 m[SRT_MAX_STEMS];
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < SRT_MAX_STEMS; ++s) {
+        if (s < nstems) {
+            float4 v = *reinterpret_cast<const float4*>(masks + (size_t)s * count + i);
+            v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+            m[s] = v;
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+    }
+    const float eps = 1e-10f, e1 = eps / (float)nstems;
+#pragma unroll
+    for (int s = 0; s < SRT_MAX_STEMS; ++s) {
+        if (s < nstems) {
+            float4 v = m[s];
+            v.x = (v.x + e1) / (sum.x + eps); v.y = (v.y + e1) / (sum.y + eps);
+            v.z = (v.z + e1) / (sum.z + eps); v.w = (v.w + e1) / (sum.w + eps);
+            *reinterpret_cast<float4*>(masks + (size_t)s * count + i) = v;
+        }
+    }
+}
+
+int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s)
+{
+    if (!count || nstems < 1) return 0;
+    hipLaunchKernelGGL(srt_ratio_mask_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, masks, nstems, count);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ------------------------------------------------------------------------------------------- streaming hop
 // Inverse of the DELAYED frame for one stem (blockIdx.x = stem): masked spectrum -> time frame -> synthesis window on the
 // last 2048 samples -> 50 % overlap-add with the kept half -> interleaved-by-8 output segment (Spleeter4Stems.c:64-101,272-320).

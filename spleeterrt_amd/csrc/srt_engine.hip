@@ -63,7 +63,7 @@ struct srt_engine {
     size_t raw_tile[6], act_tile[5], up_tile[6];       // floats per instance
     // DSP
     float *preWin, *postWin; float2* twiddle;
-    float2* spec; float* mag; float* masks; float* frames;
+    float2* spec; float2* spec2; float* mag; float* masks; float* frames;   // spec2: residual spectrum of the CLI chain (on first use)
     size_t rows_cap, frames_rows;
     int last_ntiles;
     // timing
@@ -96,7 +96,7 @@ static void free_all(srt_engine* e)
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
     for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act[i]) hipFree(e->act[i]); }
-    void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->mag, e->masks, e->frames };
+    void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->spec2, e->mag, e->masks, e->frames };
     for (void* m : misc) if (m) hipFree(m);
     for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
 }
@@ -114,7 +114,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->act, 0, sizeof e->act); memset(e->up, 0, sizeof e->up);
-    e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->mag = e->masks = e->frames = nullptr;
+    e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->spec2 = nullptr; e->mag = e->masks = e->frames = nullptr;
     e->cfg = *cfg; e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
     if (e->lo.total != SRT_COEFF_FLOATS) { delete e; return fail(-4, "internal: weight layout size mismatch"); }
     const size_t S = cfg->n_stems, NT = cfg->max_tiles, HW = (size_t)cfg->T * cfg->F;
@@ -222,21 +222,21 @@ int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 }
 
 
-int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
+// Sub-networks [s0, s0+ns) on ntiles tiles.  Buffers keep their all-stem layout (stem stride = ntiles instances), so a
+// later call for other stems of the same batch lands beside this one's results.
+static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int s0, int ns)
 {
     if (!e || !d_mag || !d_masks) return fail(-1, "srtForward: null argument");
     if (ntiles < 1 || ntiles > e->cfg.max_tiles) return fail(-1, "srtForward: ntiles exceeds max_tiles");
     const int S = e->cfg.n_stems, T = e->cfg.T, F = e->cfg.F;
-    for (int s = 0; s < S; ++s) if (!e->have_coeff[s]) return fail(-5, "srtForward: weights not set for every stem");
-    // the activation pair is per engine (spleeter.c:130-139 is per instance); the kernels take one kind per launch,
-    // so stems with different modes are launched as separate groups.
+    if (s0 < 0 || ns < 1 || s0 + ns > S) return fail(-1, "srtForward: stem range outside the engine's sub-networks");
+    for (int s = s0; s < s0 + ns; ++s) if (!e->have_coeff[s]) return fail(-5, "srtForward: weights not set for every stem");
     const size_t HW = (size_t)T * F;
     e->last_ntiles = ntiles;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
-        const int s0 = 0, ns = S;
         unsigned elu_mask = 0;
-        for (int s = 0; s < S; ++s) if (e->cfg.stem_mode[s]) elu_mask |= 1u << s;
+        for (int s = 0; s < ns; ++s) if (e->cfg.stem_mode[s0 + s]) elu_mask |= 1u << s;
         const int actE = SRT_ACT_LEAKY, actD = SRT_ACT_RELU;
         const float* cbase = e->coeff_all + (size_t)s0 * SRT_COEFF_STRIDE;
         char nm[32];
@@ -317,6 +317,26 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
     return 0;
 }
 
+int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
+{
+    if (!e) return fail(-1, "srtForward: null argument");
+    return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems);
+}
+
+int srtForwardStems(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int stem0, int nstems)
+{
+    if (!e) return fail(-1, "srtForward: null argument");
+    return forward_range(e, d_mag, ntiles, d_masks, stem0, nstems);
+}
+
+int srtRatioMask(srt_engine* e, float* d_masks, int ntiles)
+{
+    if (!e || !d_masks || ntiles < 1) return fail(-1, "srtRatioMask: bad argument");
+    TimerScope ts(e, "ratio");
+    if (srt_launch_ratio_mask(d_masks, e->cfg.n_stems, (size_t)ntiles * 2 * e->cfg.T * e->cfg.F, e->stream)) return fail(-2, "ratio-mask launch failed");
+    return 0;
+}
+
 static SrtDspTables tables_of(const srt_engine* e) { SrtDspTables t; t.preWin = e->preWin; t.postWin = e->postWin; t.twiddle = e->twiddle; return t; }
 
 int srtStftEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_spec, float* d_mag)
@@ -375,7 +395,88 @@ int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, s
     if (rc) return rc;
     rc = srtForward(e, e->mag, (int)ntiles, e->masks);
     if (rc) return rc;
+    if (e->cfg.ratio_mask && (rc = srtRatioMask(e, e->masks, (int)ntiles))) return rc;
     return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+}
+
+// iSTFT of one spectrum under ONE stem's mask (or none) into a [2][len] destination
+static int istft_one(srt_engine* e, const float2* spec, size_t rows, const float* mask_stem, float oob, float* d_dst, const char* tag)
+{
+    const int T = e->cfg.T;
+    SrtIstftParams p; memset(&p, 0, sizeof p);
+    p.spec = spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
+    p.frames = (int)rows; p.masks = mask_stem; p.nstems = 1; p.ntiles = (int)((rows + T - 1) / T);
+    p.T = T; p.F = e->cfg.F; p.oob[0] = oob;
+    p.frames_out = nullptr; p.out = d_dst; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
+    TimerScope ts(e, tag);
+    if (srt_launch_istft(p, e->stream)) return fail(-2, "istft launch failed");
+    return 0;
+}
+
+// The offline CLI's separation flows, device resident (Executable/main.c:776-798 two outputs, :845-928 three outputs).
+// Sub-network 0 is the CLI's net[0] (drum, mode 1), sub-network 1 its net[1] (vocal, mode 0)  (main.c:759-760).
+//   2: vocal = istft(mask1 . S);  accompaniment = input - vocal                                  (time-domain residual)
+//   3: drum = istft(mask0 . S);  R = S - mask0 . S;  vocal = istft(mask1(|R|) . R);  accompaniment = istft(R) - vocal
+// d_out: [stems][2][srtIstftLength(rows)] in the CLI's file order: (Vocal, Accompaniment) or (Drum, Vocal, Accompaniment).
+int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out)
+{
+    if (!e || !d_L || !d_R || !d_out) return fail(-1, "srtSeparateCli: null argument");
+    if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
+    if (e->cfg.n_stems < 2) return fail(-1, "srtSeparateCli: the engine needs sub-networks 0 (drum) and 1 (vocal)");
+    if (n < SRT_FFT) return fail(-1, "srtSeparateCli: need at least 4096 samples");
+    const int T = e->cfg.T;
+    const size_t rows = srtStftRows(n), frames = srtStftFrames(n), ntiles = (rows + T - 1) / T, len = srtIstftLength(rows);
+    if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparateCli: signal longer than max_tiles * T frames");
+    const size_t HW2 = 2 * (size_t)T * e->cfg.F;
+    float* mask0 = e->masks;                                  // stem stride of this batch = ntiles instances
+    float* mask1 = e->masks + ntiles * HW2;
+    int rc = srtStftEx(e, d_L, d_R, n, frames, rows, (float*)e->spec, e->mag);
+    if (rc) return rc;
+    if (stems == 2) {
+        if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 1, 1))) return rc;
+        if ((rc = istft_one(e, e->spec, rows, mask1, e->cfg.oob_weight[1], d_out, "istft"))) return rc;
+        TimerScope ts(e, "residual");
+        if (srt_launch_time_residual(d_L, d_R, n, d_out, len, d_out + 2 * len, e->stream)) return fail(-2, "residual launch failed");
+        return 0;
+    }
+    if (!e->spec2) HIPCHK(hipMalloc((void**)&e->spec2, (size_t)2 * e->rows_cap * SRT_SPEC_LD * sizeof(float2)));
+    if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 0, 1))) return rc;
+    if ((rc = istft_one(e, e->spec, rows, mask0, e->cfg.oob_weight[0], d_out, "istft"))) return rc;                 // Drum
+    {
+        SrtResidualParams r; memset(&r, 0, sizeof r);
+        r.spec = e->spec; r.res = e->spec2; r.spec_ch_stride = rows * SRT_SPEC_LD; r.rows = (int)rows; r.T = T; r.F = e->cfg.F;
+        r.mask = mask0; r.oob = e->cfg.oob_weight[0]; r.mag = e->mag;
+        TimerScope ts(e, "residual");
+        if (srt_launch_residual(r, e->stream)) return fail(-2, "residual launch failed");
+    }
+    if ((rc = istft_one(e, e->spec2, rows, nullptr, 1.0f, d_out + 4 * len, "istft"))) return rc;                      // accompaniment + vocal
+    if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 1, 1))) return rc;
+    if ((rc = istft_one(e, e->spec2, rows, mask1, e->cfg.oob_weight[1], d_out + 2 * len, "istft"))) return rc;       // Vocal
+    TimerScope ts(e, "residual");
+    if (srt_launch_time_residual(d_out + 4 * len, d_out + 5 * len, len, d_out + 2 * len, len, d_out + 4 * len, e->stream)) return fail(-2, "residual launch failed");
+    return 0;
+}
+
+// Host-buffer convenience over srtSeparateCli for plain-C callers (the CLI harness): H2D, chain, D2H, synchronous.
+int srtSeparateCliHost(srt_engine* e, const float* h_L, const float* h_R, size_t n, int stems, float* h_out)
+{
+    if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateCliHost: null argument");
+    if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
+    const size_t len = srtIstftLength(srtStftRows(n));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_in, 2 * n * sizeof(float)));
+    if (hipMalloc((void**)&d_out, (size_t)stems * 2 * len * sizeof(float)) != hipSuccess) { hipFree(d_in); return fail(-2, "srtSeparateCliHost: hipMalloc failed"); }
+    hipError_t er = hipMemcpyAsync(d_in, h_L, n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(d_in + n, h_R, n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    int rc = er == hipSuccess ? srtSeparateCli(e, d_in, d_in + n, n, stems, d_out) : fail(-2, "HIP error: %s", hipGetErrorString(er));
+    if (!rc) {
+        er = hipMemcpyAsync(h_out, d_out, (size_t)stems * 2 * len * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+        if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+        if (er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
+    }
+    hipStreamSynchronize(e->stream);
+    hipFree(d_in); hipFree(d_out);
+    return rc;
 }
 
 int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_out)

@@ -99,6 +99,20 @@ struct SrtIstftParams {
 int srt_launch_stft(const SrtStftParams& p, hipStream_t s);
 int srt_launch_istft(const SrtIstftParams& p, hipStream_t s);
 
+// residual chain of the offline CLI (main.c:845-866): res = spec - spec*mask (bins >= F: spec - spec*oob), |res|*4096 -> mag
+struct SrtResidualParams {
+    const float2* spec; float2* res; size_t spec_ch_stride;
+    int rows, T, F;
+    const float* mask;        // ONE stem: [ntiles][2][T][F]
+    float oob;
+    float* mag;               // [ntiles][2][T][F]
+};
+int srt_launch_residual(const SrtResidualParams& p, hipStream_t s);
+// out[c][i] = (i < na ? a[c][i] : 0) - b[c][i], i < nb, two channels (time-domain residual, main.c:794-798, 924-928)
+int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s);
+// cross-stem ratio mask, in place on [nstems][count]: m_s <- (m_s^2 + eps/S) / (sum_j m_j^2 + eps)
+int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s);
+
 // streaming (srt_dsp.hip kernels, srt_stream.hip host logic): one hop = 1 forward + 4 masked inverse FFTs + 50 % OLA
 struct SrtStreamHop {
     const float* ring;        // [2][4096] device copy of the input ring buffer

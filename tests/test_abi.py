@@ -70,3 +70,31 @@ def test_product_never_imports_oracle():
     for f in ("capi.py", "build.py", "stream.py", "__init__.py"):
         txt = open(os.path.join(pkg, f)).read()
         assert "pyoracle" not in txt and "liboracle" not in txt
+
+
+def test_cli_argument_and_input_validation(tmp_path):
+    """host/spleeterrt_cli rejects what it cannot do BEFORE touching the GPU: usage, non-WAVE input, wrong sample rate,
+    missing weights (it has no resampler / FLAC / MP3 decoder and no embedded model — see its header)."""
+    import struct
+    import subprocess
+    host = os.path.join(ROOT, "host")
+    cli = os.path.join(host, "spleeterrt_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", host, "spleeterrt_cli"])
+    env = {k: v for k, v in os.environ.items() if k != "SPLEETERRT_WEIGHTS"}
+    r = subprocess.run([cli], capture_output=True, env=env)
+    assert r.returncode != 0 and b"spawnNthreads timeStep analyseBinLimit stems" in r.stdout
+    bad = tmp_path / "x.flac"
+    bad.write_bytes(b"fLaC" + bytes(64))
+    w = tmp_path / "w.f16"
+    w.write_bytes(b"")
+    r = subprocess.run([cli, "1", "64", "512", "2", str(bad), str(w)], capture_output=True, env=env)
+    assert r.returncode != 0 and b"not a RIFF/WAVE" in r.stderr
+    wav = tmp_path / "a.wav"
+    pcm = bytes(4 * 100)
+    wav.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 48000, 48000 * 4, 4, 16)
+                    + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    r = subprocess.run([cli, "1", "64", "512", "2", str(wav), str(w)], capture_output=True, env=env)
+    assert r.returncode != 0 and b"only 44.1 kHz" in r.stderr
+    r = subprocess.run([cli, "1", "64", "512", "2", str(wav)], capture_output=True, env=env)
+    assert r.returncode != 0 and b"no weights" in r.stderr

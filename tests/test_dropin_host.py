@@ -73,3 +73,47 @@ def test_tile_api_via_ctypes(oracle, coeffs):
     C.CDLL(None).free.argtypes = [C.c_void_p]
     C.CDLL(None).free(nn)
     os.environ.pop("SPLEETERRT_VARIANT")
+
+
+def _write_wav16(path, L, R, rate=44100):
+    import struct
+    pcm = np.clip(np.round(np.stack([L, R], 1) * 32768.0), -32768, 32767).astype("<i2")
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, rate, rate * 4, 4, 16))
+        f.write(b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+    return pcm.astype(np.float32) / 32768.0
+
+
+def _read_wav_f32(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    i = b.index(b"data")
+    n = int.from_bytes(b[i + 4:i + 8], "little")
+    return np.frombuffer(b[i + 8:i + 8 + n], "<f4").reshape(-1, 2)
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_cli_program_matches_reference_linked_harness(workdir, oracle, stems):
+    """host/spleeterrt_cli (reference command line, WAV in / float32 WAV out, device-resident flow) against the harness
+    linked to the real reference on the same 16-bit PCM clip."""
+    cli, ref = os.path.join(HOST, "spleeterrt_cli"), os.path.join(HOST, "offline_ref")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", HOST, "spleeterrt_cli"])
+    if not os.path.exists(ref) or oracle.ref_path("exe") is None:
+        pytest.skip("reference build (oracle/_ref, host/offline_ref) not present")
+    n = 44100 * 2 + 77
+    L, R = oracle.synth_audio(n, 555, True)
+    q = _write_wav16(workdir / "clip.wav", L * 4.0, R * 4.0)
+    q.astype(np.float32).tofile(workdir / "clip.f32")
+    env = dict(os.environ, SPLEETERRT_VARIANT="exe")
+    out = subprocess.check_output([cli, "2", "64", "512", str(stems), str(workdir / "clip.wav"), str(workdir / "weights.f16")],
+                                  cwd=workdir, env=env).decode()
+    assert "Saving file -> clip.wav_Vocal.wav" in out
+    subprocess.check_call([ref, "64", "512", str(stems), str(workdir / "weights.f16"), str(workdir / "clip.f32"),
+                           str(workdir / ("cliref%d" % stems))], env=env)
+    for nm in ["Vocal", "Accompaniment"] + (["Drum"] if stems == 3 else []):
+        a = _read_wav_f32(workdir / ("clip.wav_%s.wav" % nm))
+        r = np.fromfile(workdir / ("cliref%d_%s.f32" % (stems, nm)), np.float32).reshape(-1, 2)
+        assert a.shape == r.shape == (n, 2)
+        assert _rel_rms(a, r) <= 1e-4, "%s: rel rms %g" % (nm, _rel_rms(a, r))
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max()

@@ -266,3 +266,79 @@ def test_fp16_mfma_variants(oracle, coeffs, prec, mask_tol, T, F):
     print("fp16 variant %s %dx%d worst mask err %.3g" % (prec, T, F, worst))
     assert worst <= mask_tol
     eng.close()
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_cli_flow_device_resident(oracle, coeffs, stems):
+    """srtSeparateCli == the offline CLI's flow restated over the oracle (main.c:776-798 two outputs with the time-domain
+    residual, :845-928 three outputs with the complex-domain residual chain), ragged tail tile included."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    n = 4096 * 24 + 8192
+    L, R = oracle.synth_audio(n, 777, True)
+    eng = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=2)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    out = eng.separate_cli(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), stems).cpu().numpy()
+    ref = oracle.cli_separate(coeffs(0), coeffs(1), L, R, F, T, stems, oracle.VARIANT_VST, 0.1)
+    assert out.shape == ref.shape
+    peak = np.abs(ref).max()
+    for k in range(stems):
+        assert _rel_rms(out[k], ref[k]) <= 1e-4, "output %d rel rms %g" % (k, _rel_rms(out[k], ref[k]))
+        assert np.abs(out[k] - ref[k]).max() <= 1e-4 * peak
+    # the outputs of either flow add back up to the (reconstructed) input
+    total = out.sum(axis=0)[:, 4096:n - 4096]
+    assert np.abs(total[0] - L[4096:n - 4096]).max() <= 2e-5 and np.abs(total[1] - R[4096:n - 4096]).max() <= 2e-5
+    eng.close()
+
+
+def test_forward_stem_range_equals_full(oracle, coeffs):
+    """srtForwardStems on [1,2) then [0,1) fills the same mask tensor as one srtForward over both sub-networks."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    x = torch.from_numpy(_mag_input(oracle, 2, T, F)).cuda()
+    eng = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=2)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    full = eng.forward(x).clone()
+    part = torch.zeros_like(full)
+    eng.forward_stems(x, part, 1, 1)
+    eng.forward_stems(x, part, 0, 1)
+    assert torch.equal(full, part)
+    with pytest.raises(srt.EngineError):
+        eng.forward_stems(x, part, 1, 2)
+    eng.close()
+
+
+def test_ratio_mask(oracle, coeffs):
+    """Optional cross-stem ratio mask: kernel vs the numpy restatement, and the end-to-end switch."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    S = 3
+    m = (oracle.lcg(99, S * 2 * 2 * T * F, 1.0) + 0.5).reshape(S, 2, 2, T, F).astype(np.float32)
+    m[0, 0, 0, 0, :8] = 0.0
+    m[1, 0, 0, 0, :8] = 0.0
+    m[2, 0, 0, 0, :4] = 0.0                                  # all-zero bins: eps keeps them finite (1/S each)
+    eng = _engine(F=F, T=T, stem_modes=(1, 1, 1), variant=srt.VARIANT_VST, max_tiles=2)
+    got = eng.ratio_mask(torch.from_numpy(m).cuda()).cpu().numpy()
+    ref = oracle.ratio_mask(m)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-7
+    assert np.abs(got.sum(axis=0) - 1.0).max() <= 1e-6
+    eng.close()
+
+    n = 4096 * 12 + 8192
+    L, R = oracle.synth_audio(n, 31, True)
+    eng = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=1, ratio_mask=True)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = eng.separate(Ld, Rd).cpu().numpy()
+    spec, mag = eng.stft(Ld, Rd)
+    masks = eng.ratio_mask(eng.forward(mag))
+    ref = eng.istft(spec, masks).cpu().numpy()
+    assert np.array_equal(out, ref)
+    eng.close()

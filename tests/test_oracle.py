@@ -154,3 +154,46 @@ def test_oracle_vs_reference_stft(oracle):
     r3, i3 = st3.stft(L, R)
     assert np.array_equal(r3, rre) and np.array_equal(i3, rim)
     st.close(); st3.close()
+
+
+def test_ratio_mask_restatement(oracle):
+    """(m_s^2 + eps/S) / (sum m_j^2 + eps): sums to one over stems, equal masks -> 1/S, zeros stay finite."""
+    S = 4
+    m = (oracle.lcg(5, S * 1000, 1.0) + 0.5).reshape(S, 1000).astype(np.float32)
+    r = oracle.ratio_mask(m)
+    assert r.dtype == np.float32 and np.abs(r.sum(axis=0) - 1.0).max() < 1e-6
+    assert np.allclose(oracle.ratio_mask(np.full((S, 8), 0.3, np.float32)), 1.0 / S, atol=1e-7)
+    assert np.allclose(oracle.ratio_mask(np.zeros((S, 8), np.float32)), 1.0 / S, atol=1e-7)
+    a = np.zeros((2, 4), np.float32)
+    a[0] = 0.9
+    assert np.allclose(oracle.ratio_mask(a)[0], 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_cli_flow_restatement_vs_reference_linked_harness(oracle, tmp_path, stems):
+    """oracle.cli_separate (main.c:776-798, 845-928 restated) against host/offline_main.c linked to the REAL reference
+    (oracle/_ref): same padded input, same fp16-container weights, EXE flavour.  Pins the residual arithmetic and the
+    output order of the two- and three-output flows."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "host", "offline_ref")
+    if oracle.ref_path("exe") is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    if not os.path.exists(ref):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "host"), "offline_ref"])
+    T, F, n = 64, 512, 44100 + 321
+    h0, h1 = oracle.synth_coeff_fp16(1), oracle.synth_coeff_fp16(0)          # container order: net[0] drum, net[1] vocal
+    np.concatenate([h0, h1]).tofile(tmp_path / "w.f16")
+    L, R = oracle.synth_audio(n, 321, True)
+    np.stack([L, R], 1).astype(np.float32).tofile(tmp_path / "in.f32")
+    subprocess.check_call([ref, str(T), str(F), str(stems), str(tmp_path / "w.f16"), str(tmp_path / "in.f32"), str(tmp_path / "o")])
+    final = 4096 * ((n + 4095) // 4096) + 8192
+    pL, pR = np.zeros(final, np.float32), np.zeros(final, np.float32)
+    pL[4096:4096 + n], pR[4096:4096 + n] = L, R
+    got = oracle.cli_separate(oracle.fp16_expand(h0), oracle.fp16_expand(h1), pL, pR, F, T, stems, oracle.VARIANT_EXE, 0.1)
+    names = ["Vocal", "Accompaniment"] if stems == 2 else ["Drum", "Vocal", "Accompaniment"]
+    for k, nm in enumerate(names):
+        r = np.fromfile(tmp_path / ("o_%s.f32" % nm), np.float32).reshape(-1, 2)
+        a = got[k][:, 4096:4096 + n].T
+        assert a.shape == r.shape
+        assert np.abs(a - r).max() <= 2e-6 * max(np.abs(r).max(), 1e-3), "%s: %g" % (nm, np.abs(a - r).max())
