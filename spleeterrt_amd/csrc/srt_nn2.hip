@@ -72,6 +72,23 @@ template <int TW, int SW> struct Enc2Pad {
     static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
 };
 
+// Scheduling hint for the unrolled chunk body: LDS operand reads run PRO reads ahead of the MFMAs that consume them and are
+// then issued two per M1 + M2 MFMAs, so each s_waitcnt can leave the younger reads in flight (lgkmcnt(n > 0)) instead of draining
+// the LDS queue right before every MFMA burst.  Pure instruction order: no effect on results.
+template <int NMFMA, int PRO, int M1, int M2>
+__device__ __forceinline__ void srt_mfma_pipeline()
+{
+#pragma unroll
+    for (int i = 0; i < PRO; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int i = 0; i < NMFMA / (M1 + M2); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, M1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, M2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+}
+
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
@@ -186,6 +203,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
             }
         }
+        if (ABL == 0) srt_mfma_pipeline<(KC / 2) * 25 * MR * NR, 16, 1, 2>();
         __syncthreads();                                   // everyone is done with s_in and slab (ch&1)
     }
 
@@ -346,6 +364,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
                         acc[cls][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[sh][nr], acc[cls][mr][nr], 0, 0, 0);
             }
         }
+        if (ABL == 0) srt_mfma_pipeline<(KC / 2) * NTAP * MR * NR, 12, 2, 2>();
         if (ABL != 2) __syncthreads();
     }
 
@@ -573,10 +592,10 @@ static int tune(const char* key)
 {
     const char* e = getenv("SRT_TUNE");
     if (!e) return 0;
-    const char* q = strstr(e, key);
-    if (!q) return 0;
-    q += strlen(key);
-    return *q == '=' ? atoi(q + 1) : 0;
+    const size_t n = strlen(key);
+    for (const char* q = e; (q = strstr(q, key)) != nullptr; q += n)
+        if ((q == e || q[-1] == ',') && q[n] == '=') return atoi(q + n + 1);          // whole key only ("abl" is not "eabl")
+    return 0;
 }
 
 int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
@@ -617,6 +636,7 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
             if (abl == 4) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
             if (abl == 5) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
             if (abl == 7) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 7>), grid, dim3(256), 0, s, p);
+            if (abl == 8) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 8>), grid, dim3(256), 0, s, p);   // no scheduling hint
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
         return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);
@@ -668,6 +688,7 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
             if (abl == 4) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
             if (abl == 5) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
             if (abl == 6) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 6>), grid, dim3(256), 0, s, p);
+            if (abl == 8) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 8>), grid, dim3(256), 0, s, p);   // no scheduling hint
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
         return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);
