@@ -86,6 +86,12 @@ SRT_API int  srtSeparate(srt_engine *e, const float *d_L, const float *d_R, size
 SRT_API int  srtStftEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_spec, float *d_mag);
 SRT_API int  srtSeparateEx(srt_engine *e, const float *d_L, const float *d_R, size_t n, size_t frames, size_t rows, float *d_out);
 
+/* A long HOST-resident stream through one GPU: cut into chunks of max_tiles tiles, upload / compute / download overlapped on
+ * three HIP streams with double buffers, chunk overlaps (3072 samples) added on the device.  Geometry as srtSeparateEx.
+ * h_out: [n_stems][2][srtIstftLength(rows)].  Synchronous; replaces main()'s whole-file stft -> processMT -> istft
+ * (Executable/main.c:776-785) for inputs of any length (the reference holds the full 4096-wide spectrogram in RAM). */
+SRT_API int  srtSeparateHostStream(srt_engine *e, const float *h_L, const float *h_R, size_t n, size_t frames, size_t rows, float *h_out);
+
 /* The offline CLI's flows (Executable/main.c:776-798 for stems == 2, :845-928 for stems == 3), everything in HBM.
  * Sub-network 0 = the CLI's net[0] (drum, stem_mode 1), sub-network 1 = net[1] (vocal, stem_mode 0)  (main.c:759-760).
  * d_out: [stems][2][srtIstftLength(srtStftRows(n))] in the CLI's output order: Vocal, Accompaniment | Drum, Vocal, Accompaniment. */

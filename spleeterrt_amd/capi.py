@@ -48,6 +48,7 @@ def load_library():
     L.srtRatioMask.argtypes = [vp, f32p, C.c_int]
     L.srtSeparateCli.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_int, f32p]
     L.srtSeparateCliHost.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+    L.srtSeparateHostStream.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
     for fn in (L.srtStftRows, L.srtStftFrames, L.srtIstftLength):
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_size_t]
@@ -184,6 +185,21 @@ class Engine:
         n = L.numel()
         out = t.empty((stems, 2, self.L.srtIstftLength(self.L.srtStftRows(n))), device=self.device, dtype=t.float32)
         self._chk(self.L.srtSeparateCli(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, stems, _ptr(out)))
+        return out
+
+    def separate_host_stream(self, L, R, frames=None, rows=None, out=None):
+        """host numpy PCM of any length -> host numpy stems [S,2,rows*1024+3072]; chunks of max_tiles tiles with the
+        PCIe copies overlapped with compute (srtSeparateHostStream)."""
+        import numpy as np
+        L = np.ascontiguousarray(L, np.float32)
+        R = np.ascontiguousarray(R, np.float32)
+        n = L.size
+        rows = self.L.srtStftRows(n) if rows is None else rows
+        frames = self.L.srtStftFrames(n) if frames is None else frames
+        if out is None:
+            out = np.empty((self.S, 2, self.L.srtIstftLength(rows)), np.float32)
+        self._chk(self.L.srtSeparateHostStream(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), n, frames, rows,
+                                               C.c_void_p(out.ctypes.data)))
         return out
 
     def separate_ex(self, L, R, frames, rows, out=None):

@@ -347,6 +347,24 @@ int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Overlap-add across the chunks of a long stream: consecutive chunks share 3072 output samples (three hops of the last
+// frames' tails, stftFix.c:570-575).  The previous chunk's tail is added to this chunk's head and this chunk's tail is kept.
+__global__ void __launch_bounds__(256) srt_carry_kernel(float* out, size_t plane_len, size_t tail, float* carry, int first, int last)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, pl = blockIdx.y;         // i < 3072
+    float* o = out + (size_t)pl * plane_len;
+    float* c = carry + (size_t)pl * (SRT_FFT - SRT_HOP);
+    if (!first) o[i] += c[i];
+    if (!last) c[i] = o[tail + i];                                         // tail >= 3072 for every chunk but the last
+}
+
+int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, float* carry, int first, int last, hipStream_t s)
+{
+    if (first && last) return 0;
+    hipLaunchKernelGGL(srt_carry_kernel, dim3((SRT_FFT - SRT_HOP) / 256, nplanes), dim3(256), 0, s, out, plane_len, tail, carry, first, last);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // Cross-stem ratio mask (what official Spleeter applies and the reference deliberately leaves out, README.MD:82-85):
 // every stem's mask is squared and normalised by the sum over stems at the same (tile, channel, frame, bin).
 __global__ void __launch_bounds__(256) srt_ratio_mask_kernel(float* masks, int nstems, size_t count)

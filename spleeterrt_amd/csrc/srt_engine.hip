@@ -485,6 +485,89 @@ int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, flo
     return srtSeparateEx(e, d_L, d_R, n, srtStftFrames(n), srtStftRows(n), d_out);
 }
 
+// Long host-resident stream through one GPU: the stream is cut into chunks of max_tiles tiles (tiles are independent,
+// main.c:455-495); chunk c+1's PCM goes up and chunk c-1's stems come down on two copy streams while chunk c computes,
+// and the 3072-sample overlap between consecutive chunks is added on the device (srt_carry_kernel), so every output
+// sample crosses PCIe exactly once.  Geometry as srtSeparateEx (a tile range of a longer stream: rows = whole tiles,
+// frames = rows; the whole stream: rows = srtStftRows(n), frames = srtStftFrames(n)).
+int srtSeparateHostStream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out)
+{
+    if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateHostStream: null argument");
+    if (rows < 1 || frames > rows) return fail(-1, "srtSeparateHostStream: need 1 <= frames <= rows");
+    const int S = e->cfg.n_stems, T = e->cfg.T, NP = S * 2;
+    const size_t chunk_rows = (size_t)e->cfg.max_tiles * T, tail = SRT_FFT - SRT_HOP;
+    const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows, total_len = srtIstftLength(rows);
+    const size_t in_cap = chunk_rows * SRT_HOP + tail, out_cap = srtIstftLength(chunk_rows);
+    float *d_in[2] = { nullptr, nullptr }, *d_out[2] = { nullptr, nullptr }, *d_carry = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_cmp[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
+    // pinning the caller's buffers lets the copies run asynchronously; if the pages are already pinned (or cannot be), carry on
+    const bool pinL = hipHostRegister((void*)h_L, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+    const bool pinR = hipHostRegister((void*)h_R, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+    const bool pinO = hipHostRegister((void*)h_out, (size_t)NP * total_len * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    int rc = 0;
+    hipError_t er = hipSuccess;
+#define STEP(x) do { if (er == hipSuccess) er = (x); } while (0)
+    for (int b = 0; b < 2; ++b) {
+        STEP(hipMalloc((void**)&d_in[b], 2 * in_cap * sizeof(float)));
+        STEP(hipMalloc((void**)&d_out[b], (size_t)NP * out_cap * sizeof(float)));
+        STEP(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
+        STEP(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming));
+        STEP(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+    }
+    STEP(hipMalloc((void**)&d_carry, (size_t)NP * tail * sizeof(float)));
+    STEP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    STEP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    for (size_t c = 0; c < nchunks && er == hipSuccess && rc == 0; ++c) {
+        const int b = (int)(c & 1);
+        const size_t row0 = c * chunk_rows, row1 = row0 + chunk_rows < rows ? row0 + chunk_rows : rows, crow = row1 - row0;
+        const size_t s0 = row0 * SRT_HOP, send = row1 * SRT_HOP + tail < n ? row1 * SRT_HOP + tail : n;
+        const size_t ns = send > s0 ? send - s0 : 0;
+        const size_t cfr = frames > row0 ? (frames - row0 < crow ? frames - row0 : crow) : 0;
+        const size_t clen = srtIstftLength(crow);
+        // upload: the input buffer is free once the compute that read it two chunks ago has finished
+        if (c >= 2) STEP(hipStreamWaitEvent(s_in, ev_cmp[b], 0));
+        if (ns) {
+            STEP(hipMemcpyAsync(d_in[b], h_L + s0, ns * sizeof(float), hipMemcpyHostToDevice, s_in));
+            STEP(hipMemcpyAsync(d_in[b] + in_cap, h_R + s0, ns * sizeof(float), hipMemcpyHostToDevice, s_in));
+        }
+        STEP(hipEventRecord(ev_in[b], s_in));
+        // compute: needs this chunk's PCM and the output buffer drained by the download of two chunks ago
+        STEP(hipStreamWaitEvent(e->stream, ev_in[b], 0));
+        if (c >= 2) STEP(hipStreamWaitEvent(e->stream, ev_out[b], 0));
+        if (er != hipSuccess) break;
+        rc = srtSeparateEx(e, d_in[b], d_in[b] + in_cap, ns, cfr, crow, d_out[b]);
+        if (rc) break;
+        if (srt_launch_carry(d_out[b], clen, NP, crow * SRT_HOP, d_carry, c == 0, c + 1 == nchunks, e->stream)) { rc = fail(-2, "carry launch failed"); break; }
+        STEP(hipEventRecord(ev_cmp[b], e->stream));
+        // download: every plane's [0, crow*1024) (+ the final 3072 on the last chunk) lands at its place in h_out
+        STEP(hipStreamWaitEvent(s_out, ev_cmp[b], 0));
+        const size_t take = c + 1 == nchunks ? clen : crow * SRT_HOP;
+        STEP(hipMemcpy2DAsync(h_out + s0, total_len * sizeof(float), d_out[b], clen * sizeof(float), take * sizeof(float), NP, hipMemcpyDeviceToHost, s_out));
+        STEP(hipEventRecord(ev_out[b], s_out));
+    }
+#undef STEP
+    if (s_in) hipStreamSynchronize(s_in);
+    hipStreamSynchronize(e->stream);
+    if (s_out) hipStreamSynchronize(s_out);
+    if (rc == 0 && er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
+    for (int b = 0; b < 2; ++b) {
+        if (d_in[b]) hipFree(d_in[b]);
+        if (d_out[b]) hipFree(d_out[b]);
+        if (ev_in[b]) hipEventDestroy(ev_in[b]);
+        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
+        if (ev_out[b]) hipEventDestroy(ev_out[b]);
+    }
+    if (d_carry) hipFree(d_carry);
+    if (s_in) hipStreamDestroy(s_in);
+    if (s_out) hipStreamDestroy(s_out);
+    if (pinL) hipHostUnregister((void*)h_L);
+    if (pinR) hipHostUnregister((void*)h_R);
+    if (pinO) hipHostUnregister((void*)h_out);
+    return rc;
+}
+
 int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_dst, size_t max_floats)
 {
     if (!e || !name || !h_dst) return fail(-1, "srtCopyTensor: null argument");

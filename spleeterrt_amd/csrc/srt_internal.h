@@ -110,6 +110,8 @@ struct SrtResidualParams {
 int srt_launch_residual(const SrtResidualParams& p, hipStream_t s);
 // out[c][i] = (i < na ? a[c][i] : 0) - b[c][i], i < nb, two channels (time-domain residual, main.c:794-798, 924-928)
 int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s);
+// chunk stitching on the device: out[p][0:3072] += carry[p] (unless first), then carry[p] = out[p][tail : tail+3072] (unless last)
+int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, float* carry, int first, int last, hipStream_t s);
 // cross-stem ratio mask, in place on [nstems][count]: m_s <- (m_s^2 + eps/S) / (sum_j m_j^2 + eps)
 int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s);
 

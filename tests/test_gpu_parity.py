@@ -186,6 +186,29 @@ def test_chunked_stream_equals_single_batch(oracle, coeffs):
     big.close(); small.close()
 
 
+@pytest.mark.parametrize("max_tiles", [1, 2, 8])
+def test_host_stream_pipeline_equals_single_batch(oracle, coeffs, max_tiles):
+    """srtSeparateHostStream (native chunking, copies overlapped with compute on three streams, overlaps carried on the
+    device) == one resident batch, for chunk sizes that divide the stream unevenly, evenly, and not at all."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    n = 4096 * 70 + 8192 + 700                                # 289 rows -> 5 tiles, ragged
+    L, R = oracle.synth_audio(n, 99, True)
+    big = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=8)
+    eng = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=max_tiles)
+    for e in (big, eng):
+        for s in range(2):
+            e.set_coeff(s, coeffs(s))
+    ref = big.separate(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    got = eng.separate_host_stream(L, R)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    again = eng.separate_host_stream(L, R)                   # reusable, deterministic
+    assert np.array_equal(got, again)
+    big.close(); eng.close()
+
+
 @pytest.mark.parametrize("T,F,stems", [(256, 1536, 1), (64, 576, 2), (128, 2048, 1), (64, 64, 1), (256, 1024, 5)])
 def test_forward_other_geometries(oracle, coeffs, T, F, stems):
     """Geometries the reference is used with: the VST default (F=1536, T=256, PluginProcessor.cpp:124), the CLI's clamp
