@@ -13,7 +13,10 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 SO = os.path.join(PKG, "libspleeterrt_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-fvisibility=hidden"]
+# SRT_TUNING=1 adds the alternative tile shapes and the ablation builds (selected at run time with SRT_TUNE=...; see
+# csrc/srt_nn2.hip); a default build holds only the shipped configuration.
+FLAGS = (["-DSRT_TUNING"] if os.environ.get("SRT_TUNING") == "1" else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-fvisibility=hidden"]
+FLAGS_TAG = os.path.join(PKG, "build", ".flags")
 
 
 def sources():
@@ -29,6 +32,10 @@ def build(force=False, verbose=True):
            [os.path.join(INC, f) for f in os.listdir(INC) if f.endswith(".h")]
     objs, procs = [], []
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    tag = " ".join(FLAGS)
+    if not os.path.exists(FLAGS_TAG) or open(FLAGS_TAG).read() != tag:      # flags changed (e.g. SRT_TUNING toggled): rebuild all
+        force = True
+        open(FLAGS_TAG, "w").write(tag)
     for src in sources():
         obj = os.path.join(PKG, "build", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)

@@ -652,14 +652,17 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
-        const char* tv = getenv("SRT_TUNE_UP6");
-        const int v = tv ? atoi(tv) : 0;
 #define UP6_LAUNCH(TH, TW) hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), 1, p.nstems * p.ntiles), dim3(256), 0, s, p)
+        int v = 0;
+#ifdef SRT_TUNING
+        const char* tv = getenv("SRT_TUNE_UP6");
+        v = tv ? atoi(tv) : 0;
         if (v == 1) UP6_LAUNCH(16, 32);
         else if (v == 5) UP6_LAUNCH(8, 32);
         else if (v == 3) UP6_LAUNCH(4, 64);
         else if (v == 4) UP6_LAUNCH(4, 128);
-        else UP6_LAUNCH(8, 64);                       // measured: 8x64 0.76 ms, 4x128 0.81, 4x64 0.85, 16x32 0.96, 8x32 0.98
+#endif
+        if (v == 0) UP6_LAUNCH(8, 64);                // measured: 8x64 0.76 ms, 4x128 0.81, 4x64 0.85, 16x32 0.96, 8x32 0.98
 #undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }

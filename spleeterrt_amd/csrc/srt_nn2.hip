@@ -584,10 +584,11 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Tuning hook: SRT_TUNE="down2=1,up5=2,..." selects an alternative tile shape for a layer class (measurement only;
-// the defaults below are the measured-best shapes for T=256, F=1024).
-#include <stdlib.h>
-#include <string.h>
+// Per-layer tile shapes.  Template arguments: <BM, WM, SW, NSX, NSY, NI, KC, stacked-M>.  The defaults below are the
+// measured best on MI355X at 64 tiles x 4 stems.  Building with -DSRT_TUNING (SRT_TUNING=1 python -m spleeterrt_amd.build)
+// adds the alternatives that were measured against them and the ablation builds quoted in DESIGN.md section 6, selected at
+// run time by SRT_TUNE="key=value,..." (keys down1 down2 up4 up5 abl eabl); a default build contains only the table.
+#ifdef SRT_TUNING
 static int tune(const char* key)
 {
     const char* e = getenv("SRT_TUNE");
@@ -597,6 +598,27 @@ static int tune(const char* key)
         if ((q == e || q[-1] == ',') && q[n] == '=') return atoi(q + n + 1);          // whole key only ("abl" is not "eabl")
     return 0;
 }
+template <int ABL>
+static int launch_enc2_ablation(const SrtConvParams& p, hipStream_t s)                  // wrong results, timing only
+{
+    dim3 grid(((p.W / 2 + 63) / 64) * ((p.H / 2 + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
+    hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, ABL>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int ABL>
+static int launch_dec2_ablation(const SrtConvParams& p, hipStream_t s)
+{
+    dim3 grid(((p.W + 31) / 32) * ((p.H + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
+    hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, ABL>), grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int NSX, int NSY>
+static int launch_dec16(const SrtConvParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL((srt_dec16_kernel<NSX, NSY, 4>), dim3(((p.W + 16 * NSX - 1) / (16 * NSX)) * ((p.H + NSY - 1) / NSY) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
 
 int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 {
@@ -604,18 +626,19 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     const int Wo = p.W / 2;
     if (p.Cin == 2) {                                                                    // down1, stem-stacked M
         if (!p.wpack2 || p.stack < 1) return 1;
-        if (p.stack * p.Cout > 32) {
-            switch (tune("down1")) {
-            case 1: return launch_enc2_cfg<64, 2, 32, 4, 2, 1, 2, true>(p, s);          // 2 rows x 128 cols
-            case 2: return launch_enc2_cfg<64, 1, 32, 2, 4, 1, 2, true>(p, s);          // MR = 2
-            case 3: return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 2, true>(p, s);          // 8 rows x 32 cols
-            case 4: return launch_enc2_cfg<64, 2, 32, 2, 8, 1, 2, true>(p, s);          // 8 rows x 64 cols, NR = 8
-            default: return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
-            }
+        if (p.stack * p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+#ifdef SRT_TUNING
+        switch (tune("down1")) {
+        case 1: return launch_enc2_cfg<64, 2, 32, 4, 2, 1, 2, true>(p, s);              // 2 rows x 128 cols
+        case 2: return launch_enc2_cfg<64, 1, 32, 2, 4, 1, 2, true>(p, s);              // MR = 2
+        case 3: return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 2, true>(p, s);              // 8 rows x 32 cols
+        case 4: return launch_enc2_cfg<64, 2, 32, 2, 8, 1, 2, true>(p, s);              // 8 rows x 64 cols, NR = 8
         }
-        return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+#endif
+        return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
     }
     if (p.Cout <= 32) {                                                                  // down2 (an 8x64 tile / NR = 4 measured 4 % slower)
+#ifdef SRT_TUNING
         switch (tune("down2")) {
         case 1: return launch_enc2_cfg<32, 1, 32, 1, 8, 1, 4, false>(p, s);
         case 2: return launch_enc2_cfg<32, 1, 32, 4, 2, 1, 4, false>(p, s);
@@ -623,22 +646,20 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
         case 4: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, false>(p, s);
         case 5: return launch_enc2_cfg<32, 1, 32, 1, 4, 1, 4, false>(p, s);
         case 6: return launch_enc2_cfg<32, 1, 32, 2, 2, 1, 4, false>(p, s);
-        default: return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
         }
+#endif
+        return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
     }
     if (Wo >= 64) {                                                                      // down3 / down4 class
-        const int abl = tune("eabl");                                                    // ablation builds (wrong results, timing only)
-        if (abl) {
-            constexpr int TW = 64, TH = 4;
-            dim3 grid(((Wo + TW - 1) / TW) * ((p.H / 2 + TH - 1) / TH) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
-            if (abl == 1) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 1>), grid, dim3(256), 0, s, p);
-            if (abl == 3) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 3>), grid, dim3(256), 0, s, p);
-            if (abl == 4) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
-            if (abl == 5) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
-            if (abl == 7) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 7>), grid, dim3(256), 0, s, p);
-            if (abl == 8) hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 8>), grid, dim3(256), 0, s, p);   // no scheduling hint
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+#ifdef SRT_TUNING
+        switch (tune("eabl")) {                                                          // 1 no loads, 3 constant operands, 4 no patch, 5 no DMA, 8 no scheduling hint
+        case 1: return launch_enc2_ablation<1>(p, s);
+        case 3: return launch_enc2_ablation<3>(p, s);
+        case 4: return launch_enc2_ablation<4>(p, s);
+        case 5: return launch_enc2_ablation<5>(p, s);
+        case 8: return launch_enc2_ablation<8>(p, s);
         }
+#endif
         return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);
     }
     if (Wo >= 32) return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 4, false>(p, s);            // down5 class
@@ -649,48 +670,47 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
     if (p.Cout == 16) {                                                                  // up5
-        const int v = tune("up5");
-        if (v == 0 || v >= 10) {             // default: exact-M 16x16x4 form, 4 rows x 64 columns (1.83 ms; 4x128: 1.91; class-stacked 32x32x2: 2.07)
-            if (v == 0 || v == 13) hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 4>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-            else if (v == 14) hipLaunchKernelGGL((srt_dec16_kernel<8, 2, 4>), dim3(((p.W + 127) / 128) * ((p.H + 1) / 2) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-            else if (v == 10) hipLaunchKernelGGL((srt_dec16_kernel<4, 8, 4>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-            else if (v == 12) hipLaunchKernelGGL((srt_dec16_kernel<2, 16, 4>), dim3(((p.W + 31) / 32) * ((p.H + 15) / 16) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((srt_dec16_kernel<8, 4, 4>), dim3(((p.W + 127) / 128) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+        // default: exact-M 16x16x4 form, 4 rows x 64 columns (1.83 ms; 4x128: 1.91; class-stacked 32x32x2: 2.07)
+#ifdef SRT_TUNING
+        switch (tune("up5")) {
+        case 10: return launch_dec16<4, 8>(p, s);
+        case 11: return launch_dec16<8, 4>(p, s);
+        case 12: return launch_dec16<2, 16>(p, s);
+        case 14: return launch_dec16<8, 2>(p, s);
+        case 1: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s) : 1;   // class-stacked 32x32x2 forms (83 % row efficiency)
+        case 2: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s) : 1;
+        case 3: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s) : 1;
+        case 4: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 1, 4, 1, 4, true>(p, s) : 1;
+        case 5: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 8, true>(p, s) : 1;
+        case 6: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 1, 8, 1, 8, true>(p, s) : 1;
+        case 7: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s) : 1;
         }
-        if (!p.wpack2) return 1;
-        switch (v) {                                                                     // class-stacked 32x32x2 forms (83 % row efficiency)
-        case 1: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s);
-        case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s);
-        case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
-        case 4: return launch_dec2_cfg<32, 1, 32, 1, 4, 1, 4, true>(p, s);
-        case 5: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 8, true>(p, s);
-        case 6: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 8, true>(p, s);
-        default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, true>(p, s);
-        }
+#endif
+        hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 4>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     if (p.Cout <= 32) {                                                                  // up4 (KC = 8 measured 5 % slower)
+#ifdef SRT_TUNING
         switch (tune("up4")) {
         case 1: return launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, false>(p, s);
         case 2: return launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, false>(p, s);
         case 3: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, false>(p, s);
-        default: return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
         }
+#endif
+        return launch_dec2_cfg<32, 1, 32, 2, 4, 1, 4, false>(p, s);
     }
     if (p.W >= 32) {                                                                     // up2 / up3
-        const int abl = tune("abl");                                                     // ablation builds (wrong results, timing only)
-        if (abl) {
-            constexpr int TW = 32, TH = 4;
-            dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
-            if (abl == 1) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 1>), grid, dim3(256), 0, s, p);
-            if (abl == 2) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 2>), grid, dim3(256), 0, s, p);
-            if (abl == 3) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 3>), grid, dim3(256), 0, s, p);
-            if (abl == 4) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 4>), grid, dim3(256), 0, s, p);
-            if (abl == 5) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 5>), grid, dim3(256), 0, s, p);
-            if (abl == 6) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 6>), grid, dim3(256), 0, s, p);
-            if (abl == 8) hipLaunchKernelGGL((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 8>), grid, dim3(256), 0, s, p);   // no scheduling hint
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+#ifdef SRT_TUNING
+        switch (tune("abl")) {                                                           // 1 no loads, 2 no barriers, 3 constant operands, 4 no patch, 5 no DMA, 6 DMA from one address, 8 no scheduling hint
+        case 1: return launch_dec2_ablation<1>(p, s);
+        case 2: return launch_dec2_ablation<2>(p, s);
+        case 3: return launch_dec2_ablation<3>(p, s);
+        case 4: return launch_dec2_ablation<4>(p, s);
+        case 5: return launch_dec2_ablation<5>(p, s);
+        case 6: return launch_dec2_ablation<6>(p, s);
+        case 8: return launch_dec2_ablation<8>(p, s);
         }
+#endif
         return launch_dec2_cfg<64, 2, 32, 1, 4, 1, 4, false>(p, s);
     }
     return launch_dec2_cfg<64, 2, 16, 1, 2, 2, 4, false>(p, s);                          // up1

@@ -389,8 +389,10 @@ int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
 {
     if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 32) return 1;       // down1 (Cin = 2) stays on the fp32 kernel
     const int Wo = p.W / 2;
-    const char* tv = getenv("SRT_TUNE16");
-    const int v = tv ? atoi(tv) : (p.nsplit == 2 ? 1 : 0);       // the split variant doubles the patch planes: bigger tiles measured faster there
+    int v = p.nsplit == 2 ? 1 : 0;                               // the split variant doubles the patch planes: bigger tiles measured faster there
+#ifdef SRT_TUNING
+    if (const char* tv = getenv("SRT_TUNE16")) v = atoi(tv);
+#endif
     if (Wo >= 64) {
         if (v == 1) return launch_enc16<32, 2, 4, 1>(p, s);                  // 4 rows x 64 cols: 99 KB LDS, 1 workgroup / CU
         if (v == 2) return launch_enc16<32, 2, 2, 1>(p, s);                  // 2 rows x 64 cols
