@@ -7,6 +7,8 @@
 //              tap-MFMAs per channel pair                                            ("class-stacked")
 // Requires W % 4 == 0 (every level of T,F multiples of 128; otherwise the v1 kernels run).
 #include "srt_device.h"
+#include <stdlib.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------- stacked weight packing
 // down1: wp2[(ci*25+tap)*CP2 + stem*Cout + co] = w_stem[co][ci][tap]
