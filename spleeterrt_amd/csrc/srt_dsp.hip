@@ -179,8 +179,9 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
 // owns segments [s0, s1) recomputes the three frames before s0 as warm-up ((G+3)/G extra work).
 // The stems of a group are processed back to back for one frame, so the spectrum row is served from L1/L2 after the first.
 template <int NS>
-__global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G, int stem0)
+__global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G)
 {
+    const int stem0 = blockIdx.y * NS;
     __shared__ float2 s_tw[FFT_TW_F2];
     __shared__ float2 s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
@@ -286,15 +287,14 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
 {
     if (p.frames <= 0) return 0;
     const int nseg = p.frames + 3;
-    int G = (nseg + 511) / 512;                       // ~2 workgroups per CU when the stream is long enough
-    if (G < 13) G = 13;                               // keep the 3-frame warm-up below ~25 %
+    // One launch for all stems (blockIdx.y = stem): ~4 workgroups per CU over the whole grid when the stream is long enough,
+    // runs of at least 13 segments so the 3-frame warm-up stays below ~25 % (64-tile batch, 4 stems: G = 65, 4.6 %).
+    int G = (int)(((size_t)nseg * p.nstems + 1023) / 1024);
+    if (G < 13) G = 13;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
-    for (int st0 = 0; st0 < p.nstems; st0 += 1) {
-        hipLaunchKernelGGL((srt_istft_ola_kernel<1>), dim3(blocks), dim3(256), 0, s, p, G, st0);
-        if (hipGetLastError() != hipSuccess) return -1;
-    }
-    return 0;
+    hipLaunchKernelGGL((srt_istft_ola_kernel<1>), dim3(blocks, p.nstems), dim3(256), 0, s, p, G);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ------------------------------------------------------------------------------------------- residual chain / ratio mask
