@@ -77,7 +77,7 @@ SRT_API size_t srtIstftLength(size_t rows);      /* rows*1024 + 3072            
 /* STFT of planar stereo PCM resident in HBM.  d_spec: [2][rows][2052] interleaved (re,im) with the reference's
  * conjugate convention; rows = srtStftRows(n).  d_mag (optional, may be NULL): [ceil(rows/T)][2][T][F]. */
 SRT_API int  srtStft(srt_engine *e, const float *d_L, const float *d_R, size_t n, float *d_spec, float *d_mag);
-/* d_masks: [n_stems][ntiles][2][T][F] (NULL = all-ones).  d_out: [n_stems][2][srtIstftLength(rows)] */
+/* d_masks: [n_stems][ntiles][2][T][F] (NULL = all-ones for bins < F; bins F..2048 always get oob_weight[stem]).  d_out: [n_stems][2][srtIstftLength(rows)] */
 SRT_API int  srtIstft(srt_engine *e, const float *d_spec, size_t rows, const float *d_masks, float *d_out);
 /* whole hot path, everything in HBM: PCM -> STFT -> |.| -> U-Nets -> mask -> iSTFT.  d_out as in srtIstft. */
 SRT_API int  srtSeparate(srt_engine *e, const float *d_L, const float *d_R, size_t n, float *d_out);

@@ -365,3 +365,46 @@ def test_ratio_mask(oracle, coeffs):
     ref = eng.istft(spec, masks).cpu().numpy()
     assert np.array_equal(out, ref)
     eng.close()
+
+
+def test_full_size_batch_properties(oracle, coeffs):
+    """BASELINE configs[2] at full size (4 stems x 64 tiles of 256x1024), through size-independent properties:
+    tiles are independent (a tile's masks do not depend on its batch mates or its slot), a T-periodic signal gives
+    identical masks in every tile, masks are finite and inside [0,1], unit masks give back the input (STFT -> iSTFT
+    identity, stftFix.c round trip), and one (tile, stem) of the batch matches the CPU oracle."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S, NT = 256, 1024, 4, 64
+    eng = _engine(F=F, T=T, stem_modes=(1,) * S, oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST, max_tiles=NT)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    n = NT * T * 1024
+    per = T * 1024
+    L1, R1 = oracle.synth_audio(per, 777, True)
+    L = torch.from_numpy(np.tile(L1, NT)).cuda()
+    R = torch.from_numpy(np.tile(R1, NT)).cuda()
+    spec, mag = eng.stft(L, R)
+    assert tuple(mag.shape) == (NT, 2, T, F)
+    masks = eng.forward(mag)
+    assert torch.isfinite(masks).all() and float(masks.min()) >= 0.0 and float(masks.max()) <= 1.0
+    # interior tiles of a T-periodic signal see identical magnitudes -> bit-identical masks, whatever their slot
+    assert torch.equal(mag[5], mag[40])
+    for j in (6, 31, 62):
+        assert torch.equal(masks[:, 5], masks[:, j]), "tile %d differs from tile 5" % j
+    # a tile evaluated alone (batch of 1, slot 0) == the same tile inside the 64-tile batch
+    alone = eng.forward(mag[17:18].contiguous())
+    assert torch.equal(alone[:, 0], masks[:, 17])
+    # one (tile, stem) against the CPU oracle at the full tile size
+    ref = oracle.forward(coeffs(2), mag[5].cpu().numpy(), 1, oracle.VARIANT_VST)
+    assert np.abs(masks[2, 5].cpu().numpy() - ref).max() <= MASK_TOL_EXACT
+    # unit masks: the inverse transform + overlap-add returns the input (away from the first / last three hops)
+    rt = _engine(F=F, T=T, stem_modes=(1,), oob_weights=(1.0,), variant=srt.VARIANT_VST, max_tiles=NT)   # bins >= F untouched too
+    back = rt.istft(spec, None)[0]
+    rt.close()
+    err = (back[:, 4096:n - 4096] - torch.stack([L, R])[:, 4096:n - 4096]).abs().max()
+    assert float(err) <= 2e-6
+    # end to end at full size: separate() == its three stages
+    out = eng.separate(L, R)
+    ref_out = eng.istft(spec, masks)
+    assert torch.equal(out, ref_out)
+    eng.close()
