@@ -15,27 +15,71 @@
 // spectrum row is read once for all stems.  Overlap-add is a deterministic 4-frame gather in frame order.
 #include "srt_internal.h"
 
-#define FFT_EX1_LD 272      // exchange-1 row stride (float2): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
-#define FFT_EX2_LD 257      // exchange-2 row stride (float2): odd -> conflict-free strided b64 writes
-#define FFT_SMEM_F2 4352    // 16*272 float2 scratch (also holds 4096 natural-order points)
+#define FFT_EX1_LD 272      // exchange-1 row stride (cf): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
+#define FFT_EX2_LD 257      // exchange-2 row stride (cf): odd -> conflict-free strided b64 writes
+#define FFT_SMEM_F2 4352    // 16*272 cf scratch (also holds 4096 natural-order points)
 
-__device__ __forceinline__ float2 f2(float x, float y) { return make_float2(x, y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return f2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex values are 2-wide vectors so the butterflies map onto the packed fp32 VALU (v_pk_add/mul/fma_f32: two lanes per
+// instruction).  The two operations the compiler does not fold into one packed instruction by itself — a +/- (-i)b and the
+// complex product — are spelled out with their op_sel / neg modifiers (half swaps and sign flips are free on VOP3P);
+// with them a radix-4 butterfly is 8 packed adds and a complex multiply is 2 packed ops (2.1x fewer VALU instructions
+// per FFT than scalar-component code run through the SLP vectoriser).
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf f2(float x, float y) { cf r = { x, y }; return r; }
+__device__ __forceinline__ cf add_mi(cf a, cf b)       // a + (-i) b = (a.x + b.y, a.y - b.x)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_mi(cf a, cf b)       // a - (-i) b = (a.x - b.y, a.y + b.x)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf cmul(cf a, cf w)         // (a.x w.x - a.y w.y, a.y w.x + a.x w.y)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                                              // (a.x w.x, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // (-a.y w.y + t.x, a.x w.y + t.y)
+    return r;
+}
+
+__device__ __forceinline__ cf herm_hi(cf b, cf a)       // (b.x + a.y, a.x - b.y)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+
+// separation of the two real spectra packed in one complex transform (z = L + iR): with zk = Z[k], zm = Z[N-k]
+__device__ __forceinline__ cf split_l(cf zk, cf zm)     // (zk.x + zm.x, zm.y - zk.y)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(r) : "v"(zk), "v"(zm));
+    return r;
+}
+__device__ __forceinline__ cf split_r(cf zk, cf zm)     // (zk.y + zm.y, zk.x - zm.x)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(zk), "v"(zm));
+    return r;
+}
 
 // forward 4-point DFT in place (W4 = -i)
-__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d)
+__device__ __forceinline__ void dft4(cf& a, cf& b, cf& c, cf& d)
 {
-    const float2 s0 = f2(a.x + c.x, a.y + c.y), s1 = f2(a.x - c.x, a.y - c.y);
-    const float2 s2 = f2(b.x + d.x, b.y + d.y), s3 = f2(b.x - d.x, b.y - d.y);
-    a = f2(s0.x + s2.x, s0.y + s2.y);
-    c = f2(s0.x - s2.x, s0.y - s2.y);
-    b = f2(s1.x + s3.y, s1.y - s3.x);
-    d = f2(s1.x - s3.y, s1.y + s3.x);
+    const cf s0 = a + c, s1 = a - c, s2 = b + d, s3 = b - d;
+    a = s0 + s2;
+    c = s0 - s2;
+    b = add_mi(s1, s3);
+    d = sub_mi(s1, s3);
 }
 
 // forward 16-point DFT, natural-order input v[n]; OUTPUT X[k] is left at v[4*(k&3) + (k>>2)]
 #define FFT16_AT(k) (4 * ((k) & 3) + ((k) >> 2))
-__device__ __forceinline__ void fft16(float2 (&v)[16])
+__device__ __forceinline__ void fft16(cf (&v)[16])
 {
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
@@ -45,7 +89,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
     v[2 + 4 * 1] = cmul(v[2 + 4 * 1], f2(r2, -r2));      // W^2
     v[3 + 4 * 1] = cmul(v[3 + 4 * 1], f2(s1, -c1));      // W^3
     v[1 + 4 * 2] = cmul(v[1 + 4 * 2], f2(r2, -r2));      // W^2
-    v[2 + 4 * 2] = f2(v[2 + 4 * 2].y, -v[2 + 4 * 2].x);  // W^4 = -i
+    v[2 + 4 * 2] = add_mi(f2(0.f, 0.f), v[2 + 4 * 2]);   // W^4 = -i
     v[3 + 4 * 2] = cmul(v[3 + 4 * 2], f2(-r2, -r2));    // W^6
     v[1 + 4 * 3] = cmul(v[1 + 4 * 3], f2(s1, -c1));      // W^3
     v[2 + 4 * 3] = cmul(v[2 + 4 * 3], f2(-r2, -r2));     // W^6
@@ -58,17 +102,18 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
 // into the order its threads read it: twA[k0-1][tid] = W^(tid*k0), twB[k1-1][lo] = W^(16*lo*k1).  All twiddle reads are
 // then consecutive or broadcast (conflict-free), instead of stride-k gathers into a 4096-entry table.
 #define FFT_TW_F2 (15 * 256 + 15 * 16)
-__device__ __forceinline__ void fft_load_twiddles(float2* tw, const float2* __restrict__ table, int tid)
+__device__ __forceinline__ void fft_load_twiddles(cf* tw, const float2* __restrict__ table_f2, int tid)
 {
+    const cf* __restrict__ table = reinterpret_cast<const cf*>(table_f2);
 #pragma unroll
     for (int k0 = 1; k0 < 16; ++k0) tw[(k0 - 1) * 256 + tid] = table[(tid * k0) & 4095];
     if (tid < 240) tw[15 * 256 + tid] = table[(16 * (tid & 15) * (tid / 16 + 1)) & 4095];
 }
 
 // 4096-point forward FFT.  In: v[n2] = x[tid + 256*n2].  Out: v[FFT16_AT(k2)] = X[tid + 256*k2].
-// s: FFT_SMEM_F2 float2 of LDS scratch, tw: the re-laid twiddles (fft_load_twiddles).
+// s: FFT_SMEM_F2 cf of LDS scratch, tw: the re-laid twiddles (fft_load_twiddles).
 // The caller must __syncthreads() before reusing s after return.
-__device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2* tw, int tid)
+__device__ __forceinline__ void fft4096(cf (&v)[16], cf* s, const cf* tw, int tid)
 {
     fft16(v);                                            // over n2 -> k0
 #pragma unroll
@@ -95,45 +140,47 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2* s, const float2
 
 __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
 {
-    __shared__ float2 s_tw[FFT_TW_F2];
-    __shared__ float2 s_x[FFT_SMEM_F2];
+    __shared__ cf s_tw[FFT_TW_F2];
+    __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
     fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
 
-    // the windowed samples of the NEXT frame are loaded while the current frame is transformed
-    float2 nxt[16];
+    // the windowed samples of the NEXT frame are loaded while the current frame is transformed (clamped frame index:
+    // a redundant reload at the end of the run instead of a conditional assignment of the 16 staged values)
+    cf nxt[16];
+    float aw[16];                                        // this thread's 16 analysis-window taps are the same for every frame
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) aw[n2] = p.tab.preWin[tid + 256 * n2];
     auto fetch = [&](int f) {
-        if (f >= p.frames_computed || f >= p.rows_total) return;         // workgroup-uniform
         const size_t pos = (size_t)f * SRT_HOP;
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int n = tid + 256 * n2;
-            const float w = p.tab.preWin[n];
             const bool ok = pos + n < p.nsamples;                        // tail frame is zero padded (stftFix.c:460-472)
             const size_t q = ok ? pos + n : 0;
-            const float l = p.L[q], r = p.R[q];
-            nxt[n2] = f2(ok ? l * w : 0.f, ok ? r * w : 0.f);
+            nxt[n2] = f2(p.L[q], p.R[q]) * (ok ? aw[n2] : 0.f);
         }
     };
-    fetch(blockIdx.x * STFT_FPB);
+    const int flast = max(p.frames_computed, 1) - 1;
+    fetch(min((int)(blockIdx.x * STFT_FPB), flast));
     for (int fi = 0; fi < STFT_FPB; ++fi) {
         const int f = blockIdx.x * STFT_FPB + fi;
         if (f >= p.rows_total) break;
         const int tile = f / p.T, t = f % p.T;
         float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
         float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
-        float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
-        float2* specR = specL + p.spec_ch_stride;
+        cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
+        cf* specR = specL + p.spec_ch_stride;
         if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
             for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
             if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
             continue;
         }
-        float2 v[16];
+        cf v[16];
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) v[n2] = nxt[n2];
-        if (fi + 1 < STFT_FPB) fetch(f + 1);
+        fetch(min(f + 1, flast));
         fft4096(v, s_x, s_tw, tid);
         __syncthreads();
 #pragma unroll
@@ -144,9 +191,8 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
         for (int j = 0; j < 9; ++j) {
             const int k = tid + 256 * j;
             if (k <= 2048) {
-                const float2 zk = s_x[k], zm = s_x[(4096 - k) & 4095];
-                const float2 sl = f2(zk.x + zm.x, zm.y - zk.y);
-                const float2 sr = f2(zk.y + zm.y, zk.x - zm.x);
+                const cf zk = s_x[k], zm = s_x[(4096 - k) & 4095];
+                const cf sl = split_l(zk, zm), sr = split_r(zk, zm);
                 specL[k] = sl;
                 specR[k] = sr;
                 if (p.mag && k < p.F) {
@@ -173,112 +219,96 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
 // Inverse STFT with the overlap-add fused in (no frame scratch, no second pass, no atomics).
 // With the radix-16 FFT's output distribution thread w holds samples w + 256*k2 of a frame, i.e. for each of the four
 // 1024-sample quarters the SAME four in-hop offsets q_j = w + 256 j.  Overlap-add across frames is therefore
-// thread-local: a workgroup walks a run of consecutive frames and keeps, per stem, a rolling window of four partial
-// output segments in registers; segment s is complete once frame s has been added (frames s-3..s, added in that
+// thread-local: a workgroup (blockIdx.y = stem) walks a run of consecutive frames and keeps a rolling window of four
+// partial output segments in registers; segment s is complete once frame s has been added (frames s-3..s, added in that
 // order = the reference's accumulation order, stftFix.c:570-575) and is written out exactly once.  A workgroup that
 // owns segments [s0, s1) recomputes the three frames before s0 as warm-up ((G+3)/G extra work).
-// The stems of a group are processed back to back for one frame, so the spectrum row is served from L1/L2 after the first.
-template <int NS>
+// The loop body is straight-line: the next frame's rows are prefetched from a CLAMPED frame index (a redundant reload
+// at the very end instead of a conditional assignment, which costs a register copy per staged value at every merge).
 __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G)
 {
-    const int stem0 = blockIdx.y * NS;
-    __shared__ float2 s_tw[FFT_TW_F2];
-    __shared__ float2 s_x[FFT_SMEM_F2];
+    const int stem = blockIdx.y;
+    __shared__ cf s_tw[FFT_TW_F2];
+    __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
     fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
     const size_t tf = (size_t)p.T * p.F;
     const int nseg = p.frames + 3;
     const int s0 = blockIdx.x * G, s1 = min(s0 + G, nseg);
-    const int nst = min(NS, p.nstems - stem0);
+    const float oob = p.oob[stem];                                           // bins >= F: "unaffectedWeight" (main.c:486-493)
+    const cf* spec = reinterpret_cast<const cf*>(p.spec);
+    float* oL = p.out + (size_t)(stem * 2 + 0) * p.out_len;
+    float* oR = p.out + (size_t)(stem * 2 + 1) * p.out_len;
 
-    float accL[NS][4][4], accR[NS][4][4];
+    cf acc[4][4];                                       // [segment slot][j] = (R, L) pairs: one packed fma per output sample pair
 #pragma unroll
-    for (int st = 0; st < NS; ++st)
+    for (int h = 0; h < 4; ++h)
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { accL[st][h][j] = 0.0f; accR[st][h][j] = 0.0f; }
+        for (int j = 0; j < 4; ++j) acc[h][j] = f2(0.0f, 0.0f);
 
-    // Software pipeline: the spectrum row and mask rows of the NEXT (frame, stem) pair are in flight while the
-    // current pair is transformed, so the global-load latency is not exposed once per FFT.
-    float2 csl[9], csr[9];
-    float cgl[9], cgr[9];
-    auto fetch = [&](int f, int st, float2 (&sl)[9], float2 (&sr)[9], float (&gl)[9], float (&gr)[9]) {
-        if (f < 0 || f >= p.frames || f >= s1 || st >= nst) return;          // workgroup-uniform
-        const int tile = f / p.T, t = f % p.T, sg = stem0 + st;
-        const float2* specL = p.spec + (size_t)f * SRT_SPEC_LD;
-        const float2* specR = specL + p.spec_ch_stride;
-        const float* mL = p.masks ? p.masks + ((size_t)(sg * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : nullptr;
-        const float oob = p.oob[sg];                                         // bins >= F: "unaffectedWeight" (main.c:486-493)
+    // Software pipeline: the spectrum row and the mask rows of the NEXT frame are in flight while the current frame is
+    // transformed, so the global-load latency is not exposed once per FFT.
+    cf sl[9], sr[9];
+    float gl[9], gr[9];
+    // fetch only ISSUES loads (no value depends on them until the next iteration): without masks the two mask rows
+    // are read from a harmless table instead of branching on the pointer
+    const bool has_mask = p.masks != nullptr;
+    auto fetch = [&](int f) {                                               // 0 <= f < p.frames
+        const int tile = f / p.T, t = f % p.T;
+        const cf* specL = spec + (size_t)f * SRT_SPEC_LD;
+        const cf* specR = specL + p.spec_ch_stride;
+        const float* mL = has_mask ? p.masks + ((size_t)(stem * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : p.tab.postWin;
+        const float* mR = has_mask ? mL + tf : p.tab.postWin;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = min(tid + 256 * j, 2048), km = min(k, p.F - 1);
             sl[j] = specL[k]; sr[j] = specR[k];
-            const float a = mL ? mL[km] : 1.0f, b = mL ? mL[tf + km] : 1.0f;
-            gl[j] = k < p.F ? a : oob; gr[j] = k < p.F ? b : oob;
+            gl[j] = mL[km]; gr[j] = mR[km];
         }
     };
-    fetch(max(s0 - 3, 0), 0, csl, csr, cgl, cgr);
-    for (int f = s0 - 3; f < s1; ++f) {
-        const bool live = f >= 0 && f < p.frames;                    // workgroup-uniform
-        if (live) {
+    float pw[16];                                       // this thread's 16 synthesis-window taps are the same for every frame
 #pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                if (st < nst) {
+    for (int k2 = 0; k2 < 16; ++k2) pw[k2] = p.tab.postWin[tid + 256 * k2];
+    const int f0 = max(s0 - 3, 0);                      // frames before 0 do not exist: the window simply starts empty
+    if (f0 < p.frames) fetch(f0);
+    for (int f = f0; f < s1; ++f) {
+        if (f < p.frames) {                             // workgroup-uniform; false only for the last three segments of the stream
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) {
-                        const int k = tid + 256 * j;
-                        if (k <= 2048) {
-                            const float reL = csl[j].x * cgl[j], imL = csl[j].y * cgl[j], reR = csr[j].x * cgr[j], imR = csr[j].y * cgr[j];
-                            // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; stored swapped (im,re): inverse-by-forward trick
-                            if (k == 0) s_x[0] = f2(reR, reL);                                // a[0] = re[0]           (stftFix.c:556-557)
-                            else if (k == 2048) s_x[2048] = f2(reR - imR, reL - imL);        // rev[2048]: re - im wins (stftFix.c:563-566)
-                            else {
-                                s_x[k] = f2(reR - imL, reL + imR);
-                                s_x[4096 - k] = f2(reR + imL, reL - imR);
-                            }
-                        }
+            for (int j = 0; j < 9; ++j) {
+                const int k = tid + 256 * j;
+                if (k <= 2048) {
+                    const float wl = k < p.F ? (has_mask ? gl[j] : 1.0f) : oob, wr = k < p.F ? (has_mask ? gr[j] : 1.0f) : oob;
+                    const cf A = sl[j] * wl, B = sr[j] * wr;                      // masked (re, im) of L and R
+                    // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; stored swapped (im,re): inverse-by-forward trick
+                    if (k == 0) s_x[0] = f2(B.x, A.x);                            // a[0] = re[0]           (stftFix.c:556-557)
+                    else if (k == 2048) s_x[2048] = f2(B.x - B.y, A.x - A.y);    // rev[2048]: re - im wins (stftFix.c:563-566)
+                    else {
+                        s_x[k] = sub_mi(B, A);                                    // (reR - imL, imR + reL)
+                        s_x[4096 - k] = herm_hi(B, A);                            // (reR + imL, reL - imR)
                     }
-                    __syncthreads();
-                    float2 v[16];
-#pragma unroll
-                    for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
-                    __syncthreads();
-                    // the staging registers are free again: put the next pair's rows in flight under this FFT
-                    if (st + 1 < nst) fetch(f, st + 1, csl, csr, cgl, cgr);
-                    else fetch(f + 1, 0, csl, csr, cgl, cgr);
-                    fft4096(v, s_x, s_tw, tid);
-#pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) {
-                        const float w = p.tab.postWin[tid + 256 * k2];
-                        const float2 y = v[FFT16_AT(k2)];                                     // swapped back: L = y.y, R = y.x
-                        accL[st][k2 >> 2][k2 & 3] += y.y * w;
-                        accR[st][k2 >> 2][k2 & 3] += y.x * w;
-                    }
-                    __syncthreads();
                 }
             }
-        } else if (f + 1 >= 0 && f + 1 < p.frames) {
-            fetch(f + 1, 0, csl, csr, cgl, cgr);                      // first live frame after the (virtual) frames before 0
+            __syncthreads();
+            cf v[16];
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
+            __syncthreads();
+            fetch(min(f + 1, p.frames - 1));            // the staging registers are free again: next frame's rows fly under this FFT
+            fft4096(v, s_x, s_tw, tid);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                acc[k2 >> 2][k2 & 3] = __builtin_elementwise_fma(v[FFT16_AT(k2)], f2(pw[k2], pw[k2]), acc[k2 >> 2][k2 & 3]);   // swapped back: L = .y, R = .x
+            }
+            __syncthreads();
         }
-        // segment f is complete: emit it, then slide the window
-        const bool emit = f >= s0;
+        if (f >= s0) {                                  // segment f is complete: emit it
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            if (st < nst) {
-                if (emit) {
-                    float* oL = p.out + (size_t)((stem0 + st) * 2 + 0) * p.out_len + (size_t)f * SRT_HOP;
-                    float* oR = p.out + (size_t)((stem0 + st) * 2 + 1) * p.out_len + (size_t)f * SRT_HOP;
+            for (int j = 0; j < 4; ++j) { oL[(size_t)f * SRT_HOP + tid + 256 * j] = acc[0][j].y; oR[(size_t)f * SRT_HOP + tid + 256 * j] = acc[0][j].x; }
+        }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { oL[tid + 256 * j] = accL[st][0][j]; oR[tid + 256 * j] = accR[st][0][j]; }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    accL[st][0][j] = accL[st][1][j]; accL[st][1][j] = accL[st][2][j]; accL[st][2][j] = accL[st][3][j]; accL[st][3][j] = 0.0f;
-                    accR[st][0][j] = accR[st][1][j]; accR[st][1][j] = accR[st][2][j]; accR[st][2][j] = accR[st][3][j]; accR[st][3][j] = 0.0f;
-                }
-            }
+        for (int j = 0; j < 4; ++j) {                   // slide the window
+            acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j]; acc[3][j] = f2(0.0f, 0.0f);
         }
     }
 }
@@ -293,7 +323,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     if (G < 13) G = 13;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
-    hipLaunchKernelGGL((srt_istft_ola_kernel<1>), dim3(blocks, p.nstems), dim3(256), 0, s, p, G);
+    hipLaunchKernelGGL(srt_istft_ola_kernel, dim3(blocks, p.nstems), dim3(256), 0, s, p, G);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -306,15 +336,15 @@ __global__ void __launch_bounds__(256) srt_residual_kernel(const SrtResidualPara
 {
     const int row = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const int tile = row / p.T, t = row % p.T;
-    const float2* src = p.spec + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
-    float2* dst = p.res + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
+    const cf* src = reinterpret_cast<const cf*>(p.spec) + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
+    cf* dst = reinterpret_cast<cf*>(p.res) + (size_t)ch * p.spec_ch_stride + (size_t)row * SRT_SPEC_LD;
     const size_t mo = ((size_t)(tile * 2 + ch) * p.T + t) * p.F;
     const float* m = p.mask + mo;
     float* mag = p.mag ? p.mag + mo : nullptr;
     for (int k = tid; k < SRT_SPEC_LD; k += 256) {
-        float2 r = f2(0.f, 0.f);
+        cf r = f2(0.f, 0.f);
         if (k <= 2048) {
-            const float2 v = src[k];
+            const cf v = src[k];
             const float g = k < p.F ? m[k] : p.oob;
             r.x = __fsub_rn(v.x, __fmul_rn(v.x, g));
             r.y = __fsub_rn(v.y, __fmul_rn(v.y, g));
@@ -406,12 +436,12 @@ int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s)
 // last 2048 samples -> 50 % overlap-add with the kept half -> interleaved-by-8 output segment (Spleeter4Stems.c:64-101,272-320).
 __global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStreamHop p)
 {
-    __shared__ float2 s_tw[FFT_TW_F2];
-    __shared__ float2 s_x[FFT_SMEM_F2];
+    __shared__ cf s_tw[FFT_TW_F2];
+    __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x, st = blockIdx.x;
     fft_load_twiddles(s_tw, p.twiddle, tid);
-    const float2* specL = p.specRow;
-    const float2* specR = p.specRow + p.specChStride;
+    const cf* specL = reinterpret_cast<const cf*>(p.specRow);
+    const cf* specR = reinterpret_cast<const cf*>(p.specRow) + p.specChStride;
     const float* mL = p.maskRow + st * p.maskStemStride;
     const float* mR = mL + p.maskChStride;
     const float oob = st == 1 ? 0.0f : 0.25f;                      // Spleeter4Stems.c:73,281
@@ -419,7 +449,7 @@ __global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStream
     for (int j = 0; j < 9; ++j) {
         const int k = tid + 256 * j;
         if (k <= 2048) {
-            const float2 sl = specL[k], sr = specR[k];
+            const cf sl = specL[k], sr = specR[k];
             float gl = oob, gr = oob;
             if (k < p.F) { gl = mL[k]; gr = mR[k]; }
             const float reL = sl.x * gl, imL = sl.y * gl, reR = sr.x * gr, imR = sr.y * gr;
@@ -432,7 +462,7 @@ __global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStream
         }
     }
     __syncthreads();
-    float2 v[16];
+    cf v[16];
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
     __syncthreads();
@@ -444,7 +474,7 @@ __global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStream
     for (int k2 = 8; k2 < 12; ++k2) {
         const int i = tid + 256 * (k2 - 8);                                   // 0..1023
         const float w0 = p.synthesisWnd[i], w1 = p.synthesisWnd[i + 1024];
-        const float2 y0 = v[FFT16_AT(k2)], y1 = v[FFT16_AT(k2 + 4)];
+        const cf y0 = v[FFT16_AT(k2)], y1 = v[FFT16_AT(k2 + 4)];
         p.out[(size_t)i * 8 + 2 * st + 0] = ovL[i] + y0.y * w0;              // mOverlapStage2dash + timeDomainOut (:313-315)
         p.out[(size_t)i * 8 + 2 * st + 1] = ovR[i] + y0.x * w0;
         ovL[i] = y1.y * w1;                                                   // :317-318
@@ -456,12 +486,12 @@ __global__ void __launch_bounds__(256) srt_stream_inverse_kernel(const SrtStream
 // of the collecting batch (Spleeter4Stems.c:261-267,322-349).
 __global__ void __launch_bounds__(256) srt_stream_forward_kernel(const SrtStreamHop p)
 {
-    __shared__ float2 s_tw[FFT_TW_F2];
-    __shared__ float2 s_x[FFT_SMEM_F2];
+    __shared__ cf s_tw[FFT_TW_F2];
+    __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
     fft_load_twiddles(s_tw, p.twiddle, tid);
     __syncthreads();
-    float2 v[16];
+    cf v[16];
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) {
         const int n = tid + 256 * n2, k = (n + p.inPos) & 4095;
@@ -473,15 +503,15 @@ __global__ void __launch_bounds__(256) srt_stream_forward_kernel(const SrtStream
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) s_x[tid + 256 * k2] = v[FFT16_AT(k2)];
     __syncthreads();
-    float2* specL = p.specRow;
-    float2* specR = p.specRow + p.specChStride;
+    cf* specL = reinterpret_cast<cf*>(p.specRow);
+    cf* specR = reinterpret_cast<cf*>(p.specRow) + p.specChStride;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const int k = tid + 256 * j;
         if (k <= 2048) {
-            const float2 zk = s_x[k], zm = s_x[(4096 - k) & 4095];
-            const float2 sl = f2(zk.x + zm.x, zm.y - zk.y);
-            const float2 sr = f2(zk.y + zm.y, zk.x - zm.x);
+            const cf zk = s_x[k], zm = s_x[(4096 - k) & 4095];
+            const cf sl = f2(zk.x + zm.x, zm.y - zk.y);
+            const cf sr = f2(zk.y + zm.y, zk.x - zm.x);
             specL[k] = sl; specR[k] = sr;
             if (k < p.F) {
                 p.magRow[k] = hypotf(sl.x, sl.y) * 4096.0f;
