@@ -130,22 +130,36 @@ __global__ void srt_head_kernel(const SrtHeadParams p)
 }
 
 
-// 4 pixels per thread along frequency: 12 aligned float4 loads feed 128 FMAs, outputs leave as float4 (W % 4 == 0)
+// Branch-free logistic for the product head kernel: one v_exp_f32 and one v_rcp_f32 (|error| < 3e-7; the parity
+// tolerance on masks is 2e-4).  The debug kernels above keep the libm form.
+__device__ __forceinline__ float srt_sigmoid_fast(float x)
+{
+    const float z = __expf(-fabsf(x));
+    const float r = __builtin_amdgcn_rcpf(1.0f + z);
+    return x >= 0.0f ? r : z * r;
+}
+
+// 4 pixels per thread along frequency: 12 aligned float4 loads feed 64 packed FMAs (the two output channels of a tap ride
+// in one v_pk_fma_f32), outputs leave as float4 (W % 4 == 0).  LUT selects the Executable's table sigmoid.
+typedef float srt_v2f __attribute__((ext_vector_type(2)));
+template <bool LUT>
 __global__ void __launch_bounds__(256) srt_head_kernel4(const SrtHeadParams p)
 {
     const int stem = blockIdx.y / p.ntiles, tile = blockIdx.y % p.ntiles;
     const size_t hw = (size_t)p.H * p.W;
     const float* x = p.src + stem * p.src_stem + tile * p.src_tile;
     float* y = p.out + stem * p.out_stem + tile * p.out_tile;
-    float wk[32];
+    srt_v2f wk[16];                                                          // (channel 0, channel 1) weight of each tap
 #pragma unroll
-    for (int i = 0; i < 32; ++i) wk[i] = p.w[stem * p.coeff_stem + i];
+    for (int i = 0; i < 16; ++i) { wk[i].x = p.w[stem * p.coeff_stem + i]; wk[i].y = p.w[stem * p.coeff_stem + 16 + i]; }
     const float b0 = p.bias[stem * p.coeff_stem], b1 = p.bias[stem * p.coeff_stem + 1];
     const int W4 = p.W >> 2;
     const size_t nq = (size_t)p.H * W4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += (size_t)gridDim.x * blockDim.x) {
         const int w0 = (int)(e % W4) * 4, h = (int)(e / W4);
-        float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+        srt_v2f a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i].x = 0.f; a[i].y = 0.f; }
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const int r = h + 2 * ky - 3;
@@ -163,15 +177,18 @@ __global__ void __launch_bounds__(256) srt_head_kernel4(const SrtHeadParams p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float v = win[i + 2 * kx + 1];                     // column w0 + i + 2kx - 3
-                    a0[i] += wk[ky * 4 + kx] * v;
-                    a1[i] += wk[16 + ky * 4 + kx] * v;
+                    const srt_v2f vv = { v, v };
+                    a[i] = __builtin_elementwise_fma(wk[ky * 4 + kx], vv, a[i]);
                 }
         }
         float4 o0, o1;
-        o0.x = srt_sigmoid(a0[0] + b0, p.variant); o0.y = srt_sigmoid(a0[1] + b0, p.variant);
-        o0.z = srt_sigmoid(a0[2] + b0, p.variant); o0.w = srt_sigmoid(a0[3] + b0, p.variant);
-        o1.x = srt_sigmoid(a1[0] + b1, p.variant); o1.y = srt_sigmoid(a1[1] + b1, p.variant);
-        o1.z = srt_sigmoid(a1[2] + b1, p.variant); o1.w = srt_sigmoid(a1[3] + b1, p.variant);
+        if (LUT) {
+            o0.x = srt_sigmoid(a[0].x + b0, 0); o0.y = srt_sigmoid(a[1].x + b0, 0); o0.z = srt_sigmoid(a[2].x + b0, 0); o0.w = srt_sigmoid(a[3].x + b0, 0);
+            o1.x = srt_sigmoid(a[0].y + b1, 0); o1.y = srt_sigmoid(a[1].y + b1, 0); o1.z = srt_sigmoid(a[2].y + b1, 0); o1.w = srt_sigmoid(a[3].y + b1, 0);
+        } else {
+            o0.x = srt_sigmoid_fast(a[0].x + b0); o0.y = srt_sigmoid_fast(a[1].x + b0); o0.z = srt_sigmoid_fast(a[2].x + b0); o0.w = srt_sigmoid_fast(a[3].x + b0);
+            o1.x = srt_sigmoid_fast(a[0].y + b1); o1.y = srt_sigmoid_fast(a[1].y + b1); o1.z = srt_sigmoid_fast(a[2].y + b1); o1.w = srt_sigmoid_fast(a[3].y + b1);
+        }
         *reinterpret_cast<float4*>(y + (size_t)h * p.W + w0) = o0;
         *reinterpret_cast<float4*>(y + hw + (size_t)h * p.W + w0) = o1;
     }
@@ -677,7 +694,8 @@ int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
     if (p.W % 4 == 0) {
         size_t bx4 = ((size_t)p.H * (p.W / 4) + 255) / 256;
         if (bx4 > 65535) bx4 = 65535;
-        hipLaunchKernelGGL(srt_head_kernel4, dim3((unsigned)bx4, p.nstems * p.ntiles), dim3(256), 0, s, p);
+        if (p.variant == 0) hipLaunchKernelGGL(srt_head_kernel4<true>, dim3((unsigned)bx4, p.nstems * p.ntiles), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(srt_head_kernel4<false>, dim3((unsigned)bx4, p.nstems * p.ntiles), dim3(256), 0, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     size_t total = (size_t)p.H * p.W, bx = (total + 255) / 256;
