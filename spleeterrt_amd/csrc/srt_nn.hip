@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // GATHERS its taps from LDS (no scatter, no atomics) with bias -> act -> BN fused.  B operands come straight from
 // global memory (every element feeds exactly one MFMA, so LDS staging would buy nothing).
 template <int TH, int TW, int CIN>
-__global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
+__global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
 {
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
     __shared__ float s_col[25 * NPAD];
@@ -576,8 +576,13 @@ __global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
         const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
         a[cp] = l31 < 25 ? v : 0.0f;
     }
-    // software pipeline: the B fragments of sub-tile s+4 are in flight while sub-tile s runs its 16 MFMAs
-    auto load_b = [&](int sub, float (&b)[CIN / 2]) {
+    // A wave owns sub-tiles wave, wave+4, ...: the B fragments of ALL of them are requested up front (NW x 16 registers), so
+    // the HBM latency is paid once per workgroup instead of once per sub-tile.
+    constexpr int NW = (NSUB + 3) / 4;
+    float b[NW][CIN / 2];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int sub = wave + 4 * i;
         const int pix = sub * 32 + l31, pr = pix / PW, pc = pix % PW;
         const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
         const bool ok = sub < NSUB && pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
@@ -585,26 +590,25 @@ __global__ void __launch_bounds__(256, 4) srt_up6_kernel(const SrtConvParams p)
 #pragma unroll
         for (int cp = 0; cp < CIN / 2; ++cp) {
             const float v = srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
-            b[cp] = ok ? v : 0.0f;
+            b[i][cp] = ok ? v : 0.0f;
         }
-    };
-    float bcur[CIN / 2], bnext[CIN / 2];
-    load_b(wave, bcur);
-    for (int sub = wave; sub < NSUB; sub += 4) {
-        load_b(sub + 4, bnext);
-        const int pix = sub * 32 + l31;
-        f32x16 acc;
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int i = 0; i < NW; ++i) {
+        const int sub = wave + 4 * i;
+        if (sub < NSUB) {                                         // wave-uniform
+            const int pix = sub * 32 + l31;
+            f32x16 acc;
 #pragma unroll
-        for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], bcur[cp], acc, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (tap < 25) s_col[tap * NPAD + pix] = acc[r];
+            for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[i][cp], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (tap < 25) s_col[tap * NPAD + pix] = acc[r];
+            }
         }
-#pragma unroll
-        for (int cp = 0; cp < CIN / 2; ++cp) bcur[cp] = bnext[cp];
     }
     __syncthreads();
     const float bi = p.bias[stem * p.coeff_stem], sc = p.bnScale[stem * p.coeff_stem], sf = p.bnShift[stem * p.coeff_stem];
@@ -687,7 +691,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 3) UP6_LAUNCH(4, 64);
         else if (v == 4) UP6_LAUNCH(4, 128);
 #endif
-        if (v == 0) UP6_LAUNCH(8, 64);                // measured: 8x64 0.76 ms, 4x128 0.81, 4x64 0.85, 16x32 0.96, 8x32 0.98
+        if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
