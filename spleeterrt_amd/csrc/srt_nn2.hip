@@ -436,10 +436,10 @@ template <int NSX, int NSY, int KC>                      // tile = NSY rows x (N
 __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p)
 {
     constexpr int TW = NSX * 16, TH = NSY, NS = NSX * NSY, NR = NS / 4;
-    static_assert(NS % 4 == 0 && KC == 4, "tile");
+    static_assert(NS % 4 == 0 && KC % 4 == 0, "tile");
     constexpr int PH = TH + 2, RW4 = (TW + 8) / 4, ROWS = TW + 8, CHS = PH * ROWS;
     constexpr int NF4 = KC * PH * RW4, NLD = (NF4 + 255) / 256;
-    constexpr int WSLAB = KC * 25 * 16;                                     // 1600 floats per chunk
+    constexpr int WROWS = KC * 25, WSLAB = (WROWS * 16 + 255) / 256 * 256;   // rows of 16 floats, whole 1-KiB DMA pieces
     __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
@@ -477,25 +477,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
             }
         }
     };
-    // weights of a chunk: KC*25 rows of 16 floats; threads 0..399 move one float4 each (plain loads: the slab is 6.4 KB)
-    float4 pwt = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_w = [&](int c0) {
-        const int e = min(tid, KC * 25 * 4 - 1) , row = e >> 2, q = e & 3;
-        pwt = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + q * 4);
-    };
-    auto store_w = [&](int buf) {
-        if (tid < KC * 25 * 4) *reinterpret_cast<float4*>(s_w + buf * WSLAB + tid * 4) = pwt;
-    };
-    // threads 256..399 do not exist (256-thread block): second pass for the remaining 144 float4
-    float4 pwt2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_w2 = [&](int c0) {
-        const int e = min(tid + 256, KC * 25 * 4 - 1), row = e >> 2, q = e & 3;
-        pwt2 = *reinterpret_cast<const float4*>(wp + ((size_t)c0 * 25 + row) * p.CP + q * 4);
-    };
-    auto store_w2 = [&](int buf) {
-        if (tid + 256 < KC * 25 * 4) *reinterpret_cast<float4*>(s_w + buf * WSLAB + (tid + 256) * 4) = pwt2;
-    };
-
+    // weights of a chunk: KC*25 rows of 16 floats, by LDS-DMA (16 rows per wave-instruction), double buffered
     f32x4 acc[4][NR];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -513,26 +495,33 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
     const int aoff = kq * 25 * 16 + l15;
 
     const int nchunks = p.Cin / KC;
-    load_patch(0); load_w(0); load_w2(0);
+    srt_dma_slab<WROWS, 16>(wp, p.CP, s_w, wave, lane);
+    load_patch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_patch(); store_w(ch & 1); store_w2(ch & 1);
-        __syncthreads();
+        store_patch();
+        __syncthreads();                                                     // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
         const float* sw = s_w + (ch & 1) * WSLAB;
-        if (ch + 1 < nchunks) { load_patch((ch + 1) * KC); load_w((ch + 1) * KC); load_w2((ch + 1) * KC); }
-        float b[9][NR];
+        if (ch + 1 < nchunks) {
+            srt_dma_slab<WROWS, 16>(wp + (size_t)(ch + 1) * KC * 25 * p.CP, p.CP, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch((ch + 1) * KC);
+        }
 #pragma unroll
-        for (int sh = 0; sh < 9; ++sh)
+        for (int kk = 0; kk < KC / 4; ++kk) {                                // one k-quad (4 channels) per MFMA k dimension
+            float b[9][NR];
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) b[sh][nr] = s_in[boff[nr] + (sh / 3) * ROWS + (sh % 3)];
+            for (int sh = 0; sh < 9; ++sh)
 #pragma unroll
-        for (int t = 0; t < 25; ++t) {
-            const int ky = t / 5, kx = t % 5, py = (ky + 1) & 1, px = (kx + 1) & 1;
-            const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
-            const int cls = py * 2 + px, sh = (dy + 1) * 3 + (dx + 1);
-            const float a = sw[aoff + t * 16];
+                for (int nr = 0; nr < NR; ++nr) b[sh][nr] = s_in[boff[nr] + kk * 4 * CHS + (sh / 3) * ROWS + (sh % 3)];
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-                acc[cls][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[sh][nr], acc[cls][nr], 0, 0, 0);
+            for (int t = 0; t < 25; ++t) {
+                const int ky = t / 5, kx = t % 5, py = (ky + 1) & 1, px = (kx + 1) & 1;
+                const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+                const int cls = py * 2 + px, sh = (dy + 1) * 3 + (dx + 1);
+                const float a = sw[aoff + (kk * 4 * 25 + t) * 16];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[cls][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[sh][nr], acc[cls][nr], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -672,13 +661,15 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
     if (p.Cout == 16) {                                                                  // up5
-        // default: exact-M 16x16x4 form, 4 rows x 64 columns (1.83 ms; 4x128: 1.91; class-stacked 32x32x2: 2.07)
+        // default: exact-M 16x16x4 form, 4 rows x 64 columns, KC = 4 (1.72 ms; KC = 8: 1.80, KC = 16: 1.87; 4x128: 1.83; class-stacked 32x32x2: 2.07)
 #ifdef SRT_TUNING
         switch (tune("up5")) {
         case 10: return launch_dec16<4, 8>(p, s);
         case 11: return launch_dec16<8, 4>(p, s);
         case 12: return launch_dec16<2, 16>(p, s);
         case 14: return launch_dec16<8, 2>(p, s);
+        case 15: hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 8>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 16: hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 16>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
         case 1: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s) : 1;   // class-stacked 32x32x2 forms (83 % row efficiency)
         case 2: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s) : 1;
         case 3: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s) : 1;
