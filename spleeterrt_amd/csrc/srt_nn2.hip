@@ -454,28 +454,31 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
     const size_t hw = (size_t)p.H * p.W;
     const float* wp = p.wpack + stem * p.wpack_stem;                        // [Cin][25][CP]
 
+    // staging geometry is chunk independent (see the encoder); a chunk's KC channels come from ONE source tensor (CA % KC == 0)
+    ptrdiff_t goff[NLD];
+    int loff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * 256, ec = min(e, NF4 - 1);
+        const int j = ec % RW4, ru = ec / RW4, r = ru % PH, c = ru / PH;
+        const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j;
+        const bool ok = e < NF4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        goff[i] = ok ? (ptrdiff_t)c * (ptrdiff_t)hw + (ptrdiff_t)gy * p.W + gx : -1;
+        loff[i] = e < NF4 ? c * CHS + r * ROWS + 4 * j : -1;
+    }
     float4 pin[NLD];
     auto load_patch = [&](int c0) {
+        const float* base = srt_src_channel(p, stem, tile, c0, hw);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int e = min(tid + i * 256, NF4 - 1);
-            const int j = e % RW4, ru = e / RW4, r = ru % PH, c = ru / PH;
-            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j;
-            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-            const float* src = srt_src_channel(p, stem, tile, c0 + c, hw);
-            const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
-            pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4*>(base + (goff[i] >= 0 ? goff[i] : 0));
+            pin[i] = goff[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            if (e < NF4) {
-                const int j = e % RW4, ru = e / RW4, r = ru % PH, c = ru / PH;
-                *reinterpret_cast<float4*>(s_in + c * CHS + r * ROWS + 4 * j) = pin[i];
-            }
-        }
+        for (int i = 0; i < NLD; ++i)
+            if (loff[i] >= 0) *reinterpret_cast<float4*>(s_in + loff[i]) = pin[i];
     };
     // weights of a chunk: KC*25 rows of 16 floats, by LDS-DMA (16 rows per wave-instruction), double buffered
     f32x4 acc[4][NR];
@@ -660,7 +663,7 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4 || p.Cout < 16) return 1;
-    if (p.Cout == 16) {                                                                  // up5
+    if (p.Cout == 16 && p.CA % 4 == 0) {                                                 // up5
         // default: exact-M 16x16x4 form, 4 rows x 64 columns, KC = 4 (1.72 ms; KC = 8: 1.80, KC = 16: 1.87; 4x128: 1.83; class-stacked 32x32x2: 2.07)
 #ifdef SRT_TUNING
         switch (tune("up5")) {
