@@ -282,29 +282,36 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     const int CPW = CLASSSTACK ? 32 : p.CP;
     const float* wp = (CLASSSTACK ? p.wpack2 + stem * p.wpack2_stem : p.wpack + stem * p.wpack_stem) + m0;
 
-    float4 pin[NLD];
-    auto load_patch_elem = [&](int c0, int i) {
-        const int e = min(tid + i * 256, NF4 - 1);
-        const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-        const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
-        const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-        const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
-        const float4 v = *reinterpret_cast<const float4*>(src + (ok ? (size_t)gy * p.W + gx : 0));
-        pin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto load_patch = [&](int c0) {
+    // staging geometry is chunk independent (see the encoder); a chunk's KC channels come from ONE source tensor (CA % KC == 0,
+    // checked by the launcher), so the source choice is workgroup-uniform per chunk
+    ptrdiff_t goff[NLD];
+    int loff[NLD], ilv[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) load_patch_elem(c0, i);
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * 256, ec = min(e, NF4 - 1);
+        const int j = ec % RW4, ru = ec / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
+        const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
+        const bool ok = e < NF4 && tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        goff[i] = ok ? (ptrdiff_t)c * (ptrdiff_t)hw + (ptrdiff_t)gy * p.W + gx : -1;
+        ilv[i] = ok ? il : 0;
+        loff[i] = e < NF4 ? c * CHS + il * INS + r * ROWS + 4 * j : -1;
+    }
+    float4 pin[NLD];
+    auto load_patch = [&](int c0) {
+        const bool fromA = c0 < p.CA;
+        const float* base = fromA ? p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile + (size_t)c0 * hw
+                                  : p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile + (size_t)(c0 - p.CA) * hw;
+        const size_t ts = fromA ? p.srcA_tile : p.srcB_tile;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (NI > 1 ? ilv[i] * ts : 0) + (goff[i] >= 0 ? goff[i] : 0));
+            pin[i] = goff[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            if (e < NF4) {
-                const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, c = ru / (PH * NI);
-                *reinterpret_cast<float4*>(s_in + c * CHS + il * INS + r * ROWS + 4 * j) = pin[i];
-            }
-        }
+        for (int i = 0; i < NLD; ++i)
+            if (loff[i] >= 0) *reinterpret_cast<float4*>(s_in + loff[i]) = pin[i];
     };
 
     f32x16 acc[NCLS][MR][NR];
@@ -662,8 +669,8 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 
 int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 {
-    if (p.W % 4 || p.Cout < 16) return 1;
-    if (p.Cout == 16 && p.CA % 4 == 0) {                                                 // up5
+    if (p.W % 4 || p.Cout < 16 || p.CA % 4) return 1;     // CA % KC: a K-chunk never straddles the two source tensors
+    if (p.Cout == 16) {                                                                  // up5
         // default: exact-M 16x16x4 form, 4 rows x 64 columns, KC = 4 (1.72 ms; KC = 8: 1.80, KC = 16: 1.87; 4x128: 1.83; class-stacked 32x32x2: 2.07)
 #ifdef SRT_TUNING
         switch (tune("up5")) {
