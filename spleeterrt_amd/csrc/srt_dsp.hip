@@ -11,8 +11,9 @@
 // entirely in registers + LDS as three radix-16 passes (16 values per thread).  Left and right channels ride in
 // the real and imaginary parts of the same transform (z = L + iR), so one FFT serves both channels of a frame;
 // the two spectra are separated in the epilogue, where the magnitude tile for the network is emitted as well.
-// The inverse uses the same FFT (swap trick) on G = F'_L + i F'_R after the per-stem mask multiply, so the
-// spectrum row is read once for all stems.  Overlap-add is a deterministic 4-frame gather in frame order.
+// The inverse uses the same FFT (swap trick) on G = F'_L + i F'_R after the per-stem mask multiply (one workgroup
+// column per stem).  Overlap-add is fused and register resident: frames are added in frame order, every output
+// sample is written once (see srt_istft_ola_kernel).
 #include "srt_internal.h"
 
 #define FFT_EX1_LD 272      // exchange-1 row stride (cf): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
