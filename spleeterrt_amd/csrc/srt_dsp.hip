@@ -15,6 +15,7 @@
 // column per stem).  Overlap-add is fused and register resident: frames are added in frame order, every output
 // sample is written once (see srt_istft_ola_kernel).
 #include "srt_internal.h"
+#include "srt_device.h"
 
 #define FFT_EX1_LD 272      // exchange-1 row stride (cf): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
 #define FFT_EX2_LD 257      // exchange-2 row stride (cf): odd -> conflict-free strided b64 writes
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
     __shared__ cf s_tw[FFT_TW_F2];
     __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
+    const int blk = blockIdx.x;                          // (XCD order measured no better here: the input is 8 KB per frame)
     fft_load_twiddles(s_tw, p.tab.twiddle, tid);
     __syncthreads();
 
@@ -164,9 +166,9 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
         }
     };
     const int flast = max(p.frames_computed, 1) - 1;
-    fetch(min((int)(blockIdx.x * STFT_FPB), flast));
+    fetch(min((int)(blk * STFT_FPB), flast));
     for (int fi = 0; fi < STFT_FPB; ++fi) {
-        const int f = blockIdx.x * STFT_FPB + fi;
+        const int f = blk * STFT_FPB + fi;
         if (f >= p.rows_total) break;
         const int tile = f / p.T, t = f % p.T;
         float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
@@ -228,7 +230,9 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
 // at the very end instead of a conditional assignment, which costs a register copy per staged value at every merge).
 __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G)
 {
-    const int stem = blockIdx.y;
+    // 1-D launch in XCD order, stem fastest: the nstems workgroups that walk the SAME run of frames sit next to each other on
+    // one XCD, so the spectrum rows the first of them pulls from HBM are L2 hits for the others (each stem re-read them before).
+    const int pos = srt_xcd_order(gridDim.x), stem = pos % p.nstems, run = pos / p.nstems;
     __shared__ cf s_tw[FFT_TW_F2];
     __shared__ cf s_x[FFT_SMEM_F2];
     const int tid = threadIdx.x;
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
     __syncthreads();
     const size_t tf = (size_t)p.T * p.F;
     const int nseg = p.frames + 3;
-    const int s0 = blockIdx.x * G, s1 = min(s0 + G, nseg);
+    const int s0 = run * G, s1 = min(s0 + G, nseg);
     const float oob = p.oob[stem];                                           // bins >= F: "unaffectedWeight" (main.c:486-493)
     const cf* spec = reinterpret_cast<const cf*>(p.spec);
     float* oL = p.out + (size_t)(stem * 2 + 0) * p.out_len;
@@ -324,7 +328,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     if (G < 13) G = 13;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
-    hipLaunchKernelGGL(srt_istft_ola_kernel, dim3(blocks, p.nstems), dim3(256), 0, s, p, G);
+    hipLaunchKernelGGL(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
