@@ -117,3 +117,28 @@ def test_cli_program_matches_reference_linked_harness(workdir, oracle, stems):
         assert a.shape == r.shape == (n, 2)
         assert _rel_rms(a, r) <= 1e-4, "%s: rel rms %g" % (nm, _rel_rms(a, r))
         assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max()
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_baseline_config0_ten_second_clip(workdir, oracle, stems):
+    """BASELINE configs[0] at its named size (and its 3-output sibling): 2-stem separation of a 10 s 44.1 kHz stereo WAV at timeStep 256 / bin limit 1024
+    (the reference CLI's `2 256 1024 2 file`), spleeterrt_cli on the GPU against the harness linked to the real reference."""
+    cli, ref = os.path.join(HOST, "spleeterrt_cli"), os.path.join(HOST, "offline_ref")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", HOST, "spleeterrt_cli"])
+    if not os.path.exists(ref) or oracle.ref_path("exe") is None:
+        pytest.skip("reference build (oracle/_ref, host/offline_ref) not present")
+    n = 441000
+    L, R = oracle.synth_audio(n, 1234, True)
+    q = _write_wav16(workdir / "ten.wav", L * 4.0, R * 4.0)
+    q.astype(np.float32).tofile(workdir / "ten.f32")
+    env = dict(os.environ, SPLEETERRT_VARIANT="exe")
+    subprocess.check_call([cli, "1", "256", "1024", str(stems), str(workdir / "ten.wav"), str(workdir / "weights.f16")], cwd=workdir, env=env,
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call([ref, "256", "1024", str(stems), str(workdir / "weights.f16"), str(workdir / "ten.f32"), str(workdir / "tenref")], env=env)
+    for nm in ["Vocal", "Accompaniment"] + (["Drum"] if stems == 3 else []):
+        a = _read_wav_f32(workdir / ("ten.wav_%s.wav" % nm))
+        r = np.fromfile(workdir / ("tenref_%s.f32" % nm), np.float32).reshape(-1, 2)
+        assert a.shape == r.shape == (n, 2)
+        assert _rel_rms(a, r) <= 1e-4, "%s: rel rms %g" % (nm, _rel_rms(a, r))
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max()
