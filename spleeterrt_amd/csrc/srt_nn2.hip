@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     constexpr int WROWS = KC * 25, WSLAB = (WROWS * BM + 255) / 256 * 256;
 
     __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
+    __shared__ float s_epi[3 * BM];                     // bias / BN scale / BN shift of this workgroup's BM rows (see the epilogue)
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
 
@@ -177,6 +178,19 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     }
     const int aoff = half * 25 * BM + wm * MR * 32 + l31;
 
+    // Epilogue constants go through LDS BEFORE the K loop.  Loaded from global memory at the start of the epilogue they put a
+    // counted s_waitcnt vmcnt(n) in front of every output element, and since stores count in vmcnt too each of those waits also
+    // drained the stores issued so far: the epilogue ran at one store round trip per element (0.36 ms of down2's 1.08 ms).
+    const bool hasBn = p.bnScale != nullptr;
+    const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
+    if (tid < BM) {
+        const int m = min(m0 + tid, mlimit - 1);
+        const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
+        const size_t ci = st * p.coeff_stem + co;
+        s_epi[tid] = p.bias[ci];
+        s_epi[BM + tid] = hasBn ? p.bnScale[ci] : 0.0f;
+        s_epi[2 * BM + tid] = hasBn ? p.bnShift[ci] : 0.0f;
+    }
     const int nchunks = p.Cin / KC;
     srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
     load_patch(0);
@@ -210,9 +224,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     }
 
     if (ABL == 7) return;                                  // ablation: no epilogue
-    const bool hasBn = p.bnScale != nullptr;
     const size_t ohw = (size_t)Ho * Wo;
-    const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         float bi[16], sc[16], sf[16];
@@ -220,12 +232,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         unsigned elu[16];                      // stem-stacked rows: the activation kind follows the row's stem
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1);
+            const int row = (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = min(m0 + row, mlimit - 1);
             const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
-            const size_t ci = st * p.coeff_stem + co;
-            bi[r] = p.bias[ci];
-            sc[r] = hasBn ? p.bnScale[ci] : 0.0f;
-            sf[r] = hasBn ? p.bnShift[ci] : 0.0f;
+            bi[r] = s_epi[row];
+            sc[r] = s_epi[BM + row];
+            sf[r] = s_epi[2 * BM + row];
             ob[r] = st * p.out_stem + (size_t)co * ohw;
             if (STEMSTACK) elu[r] = (p.elu_mask >> st) & 1u;
         }
@@ -504,6 +516,14 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
     }
     const int aoff = kq * 25 * 16 + l15;
 
+    // epilogue constants are fetched BEFORE the K loop (12 registers): fetched after it, their counted vmcnt waits would also
+    // drain the stores issued between them (see srt_enc_mfma2)
+    float bi[4], sc[4], sf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t ci = stem * p.coeff_stem + 4 * kq + r;
+        bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+    }
     const int nchunks = p.Cin / KC;
     srt_dma_slab<WROWS, 16>(wp, p.CP, s_w, wave, lane);
     load_patch(0);
@@ -536,14 +556,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
         __syncthreads();
     }
 
-    const float* bias = p.bias + stem * p.coeff_stem;
-    const float* scale = p.bnScale + stem * p.coeff_stem;
-    const float* shift = p.bnShift + stem * p.coeff_stem;
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
-    float bi[4], sc[4], sf[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const int co = 4 * kq + r; bi[r] = bias[co]; sc[r] = scale[co]; sf[r] = shift[co]; }
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int s = wave * NR + nr, sy = s / NSX, sx = s % NSX;
