@@ -241,6 +241,10 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             ob[r] = st * p.out_stem + (size_t)co * ohw;
             if (STEMSTACK) elu[r] = (p.elu_mask >> st) & 1u;
         }
+        // stem-stacked rows (down1, Cout == 16): registers 0..7 are one stem's channels and 8..15 the next stem's, so the
+        // activation parameters are two launch-uniform triples, not something to re-derive for each of the 64 outputs
+        const SrtAct apg[2] = { srt_act_params(STEMSTACK && elu[0] ? SRT_ACT_ELU : p.act, p.variant),
+                                srt_act_params(STEMSTACK && elu[8] ? SRT_ACT_ELU : p.act, p.variant) };
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int s = wn * NR + nr;
@@ -248,13 +252,30 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
             const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
             const size_t pbase = (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+            if (STEMSTACK) {
+                // a 16-row group is one stem: it is valid or not as a whole, so the 64 outputs of a thread sit behind 8 branches
+                if (pix_ok) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pix_ok && m < mlimit) {
-                    const float v = acc[mr][nr][r] + bi[r];
-                    p.outRaw[ob[r] + pbase] = v;
-                    if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], STEMSTACK ? srt_act_params(elu[r] ? SRT_ACT_ELU : p.act, p.variant) : actp);
+                    for (int g = 0; g < 2; ++g) {
+                        if (m0 + (wm * MR + mr) * 32 + 16 * g < mlimit) {
+#pragma unroll
+                            for (int r = 8 * g; r < 8 * g + 8; ++r) {
+                                const float v = acc[mr][nr][r] + bi[r];
+                                p.outRaw[ob[r] + pbase] = v;
+                                if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], apg[g]);
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && m < mlimit) {
+                        const float v = acc[mr][nr][r] + bi[r];
+                        p.outRaw[ob[r] + pbase] = v;
+                        if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], actp);
+                    }
                 }
             }
         }
@@ -640,7 +661,7 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     if (p.W % 4) return 1;
     const int Wo = p.W / 2;
     if (p.Cin == 2) {                                                                    // down1, stem-stacked M
-        if (!p.wpack2 || p.stack < 1) return 1;
+        if (!p.wpack2 || p.stack < 1 || p.Cout != 16) return 1;       // the stacked epilogue maps 16 rows to a stem
         if (p.stack * p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
 #ifdef SRT_TUNING
         switch (tune("down1")) {
