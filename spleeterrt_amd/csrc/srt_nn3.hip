@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
     constexpr int WSLAB = 25 * 512;
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
+    // bias / BN scale / BN shift of the 32 rows, staged before the K loop (see srt_enc_mfma2) - unless the tile already fills the LDS
+    constexpr bool EPI_LDS = sizeof(_Float16) * (NSPLIT * 2 * PLANE + 2 * WSLAB) + 96 * sizeof(float) <= 160 * 1024;
+    __shared__ float s_epi[EPI_LDS ? 96 : 1];
     _Float16* s_in = s_mem;
     _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
 
@@ -305,6 +308,11 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     }
     const int aoff = (g * BM + l31) * 8;
 
+    const bool hasBn = p.bnScale != nullptr;
+    if (EPI_LDS && tid < 32) {
+        const size_t ci = stem * p.coeff_stem + min(m0 + tid, p.Cout - 1);
+        s_epi[tid] = p.bias[ci]; s_epi[32 + tid] = hasBn ? p.bnScale[ci] : 0.0f; s_epi[64 + tid] = hasBn ? p.bnShift[ci] : 0.0f;
+    }
     const int nchunks = p.Cin / 16;
     srt_dma_slab16(wp, p.CP, s_w, wave, lane);
     load_patch(0);
@@ -334,16 +342,16 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
         __syncthreads();
     }
 
-    const bool hasBn = p.bnScale != nullptr;
     const size_t ohw = (size_t)Ho * Wo;
-    const float* bias = p.bias + stem * p.coeff_stem;
     float bi[16], sc[16], sf[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * g, p.Cout - 1);
-        bi[r] = bias[m];
-        sc[r] = hasBn ? p.bnScale[stem * p.coeff_stem + m] : 0.0f;
-        sf[r] = hasBn ? p.bnShift[stem * p.coeff_stem + m] : 0.0f;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (EPI_LDS) { bi[r] = s_epi[row]; sc[r] = s_epi[32 + row]; sf[r] = s_epi[64 + row]; }
+        else {
+            const size_t ci = stem * p.coeff_stem + min(m0 + row, p.Cout - 1);
+            bi[r] = p.bias[ci]; sc[r] = hasBn ? p.bnScale[ci] : 0.0f; sf[r] = hasBn ? p.bnShift[ci] : 0.0f;
+        }
     }
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
