@@ -229,6 +229,32 @@ def test_forward_other_geometries(oracle, coeffs, T, F, stems):
     eng.close()
 
 
+@pytest.mark.parametrize("T,F,ntiles,modes", [
+    (64, 128, 3, (1, 0, 1)),        # three tiles, mixed activation pairs in one launch
+    (192, 320, 2, (0,)),            # T and F that are multiples of 64 but not powers of two
+    (128, 192, 5, (1, 1)),          # odd tile count against the multi-instance tiles of down6 / up1 (NI = 4 / 2)
+    (320, 64, 2, (0, 1)),           # tall, minimal width: every layer below down1 takes the scalar-staging fallback
+    (64, 1984, 1, (1,)),            # widest non-power-of-two
+])
+def test_forward_geometry_sweep(oracle, coeffs, T, F, ntiles, modes):
+    """Forward parity on shapes chosen to hit the tile-edge, instance-group and fallback paths of the kernels (partial
+    spatial tiles, tiles-per-workgroup remainders, widths where W % 4 != 0 deep in the net)."""
+    import torch
+    import spleeterrt_amd as srt
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles)
+    for s in range(len(modes)):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=77 + T + F)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.isfinite(masks).all()
+    for s, mode in enumerate(modes):
+        for j in sorted({0, ntiles - 1}):
+            y = oracle.forward(coeffs(s), x[j], mode, oracle.VARIANT_VST)
+            d = np.abs(masks[s, j] - y).max()
+            assert d <= MASK_TOL_EXACT, "T=%d F=%d stem %d tile %d: max abs %g" % (T, F, s, j, d)
+    eng.close()
+
+
 @pytest.mark.parametrize("n", [4096, 4097, 4096 + 1023, 8192 + 5])
 def test_minimum_length_signals(oracle, coeffs, n):
     """Shortest inputs the reference accepts (one transform; below 4096 samples it underflows, stftFix.c:378):
