@@ -231,6 +231,10 @@ def main():
                          "share_of_step": sym_ms[dom] / (dt / a.steps * 1e3)},
             "nn_stack": {"achieved_tflops": nn_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "ms": nn_ms, "flop": nn_flop},
+            # the HBM-bound stages against the same guide's 8 TB/s: algorithmic bytes per frame / measured kernel time
+            "dsp_stages": {name: {"bound": "hbm", "achieved": kb * 1024.0 * rows / (avg[name] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": kb * 1024.0 * rows / (avg[name] * 1e-3) / 8e12, "algorithmic_kb_per_frame": kb}
+                           for name, kb in (("stft", 48.8), ("istft", 32.8 + STEMS * 16.0)) if name in avg},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
             "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},
         }
