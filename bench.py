@@ -46,7 +46,9 @@ LAYER_SYMBOL = {
     "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0>",
     "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",
 }
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc.json")     # written by scripts/summarize_profiles.py from separate --pmc passes
+# written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first)
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc.json")]
+N_SIMD = 1024                               # 256 CUs x 4 SIMDs: SQ_VALU_MFMA_BUSY_CYCLES is summed over them
 
 
 def synth_weights(stem, device):
@@ -79,14 +81,20 @@ def cpu_baseline(sample_tiles=None):
     flags = open("/proc/cpuinfo").read()
     flavour = "avx2" if (" avx2 " in flags and " fma " in flags and O.ref_path("avx2")) else "exe"
     kind = "reference"
+    model = next((ln.split(":", 1)[1].strip() for ln in flags.splitlines() if ln.startswith("model name")), "unknown")
+    nproc = os.cpu_count() or 1
+    try:
+        nproc_avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc_avail = nproc
     if O.ref_path(flavour) is None:
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref not built"}
-    cores = min(os.cpu_count() or 1, 64)
-    ntiles = sample_tiles or cores
+        return {"value": None, "unit": "frames/s", "cores": 0, "nproc": nproc, "cpu_model": model, "kind": "reference", "sample": "oracle/_ref not built"}
+    cores = nproc_avail                                     # every host core this process may run on: one tile per thread
+    ntiles = sample_tiles or min(max(cores, 16), 256)       # bounded sample: ~10-30 s of CPU work
     coeffs = [O.synth_coeff(s) for s in range(STEMS)]
     n = ntiles * T * HOP
     L, R = O.synth_audio(n, 777, True)
-    st = O.RefSTFT(cores=min(cores, 16), flavour=flavour)
+    st = O.RefSTFT(cores=min(cores, 16), flavour=flavour)   # the reference's STFT worker pool (stftFix.c:379-428); 16 is its practical knee
     t0 = time.time()
     re, im = st.stft(L, R)
     t_stft = time.time() - t0
@@ -110,7 +118,8 @@ def cpu_baseline(sample_tiles=None):
     st.close()
     frames = ntiles * T
     total = t_stft + t_nn + t_istft
-    return {"value": frames / total, "unit": "frames/s", "x_realtime": frames * HOP / FS / total, "cores": cores, "kind": kind,
+    return {"value": frames / total, "unit": "frames/s", "x_realtime": frames * HOP / FS / total, "cores": cores, "nproc": nproc,
+            "cpu_model": model, "kind": kind,
             "sample": "%d tiles x %d stems (%d frames): stft %.2fs + nn %.2fs + istft %.2fs; %s build of the reference C "
                       "(naive CPU_GEMM=1 GEMM, no MKL), one tile per thread as processMT" % (ntiles, STEMS, frames, t_stft, t_nn, t_istft, flavour)}
 
@@ -126,7 +135,17 @@ def main():
                     help="conv contraction arithmetic; the headline metric is f32 (other modes are separate, labelled configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0)
+    ap.add_argument("--config", default="c3", choices=["c3", "c4"],
+                    help="c3 (default, the headline): BASELINE configs[2], 64-tile batches resident in HBM.  c4: BASELINE configs[3], the "
+                         "60-minute host-resident stream partitioned by tile range over the ranks (scripts/stream_c4.py; PCIe-inclusive)")
     a = ap.parse_args()
+    if a.config == "c4":
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import stream_c4
+        res, _ = stream_c4.run(max_tiles=a.tiles, gather=False, precision=a.precision, repeats=max(1, a.steps // 10))
+        if res is not None:
+            print(json.dumps(res))
+        return
 
     import torch
     import torch.distributed as dist
@@ -167,12 +186,20 @@ def main():
     for _ in range(a.warmup):
         eng.separate(L, R, out)
     sync()
-    eng.set_timing(True)                                    # HIP events on the engine's own stream, per kernel launch
+    # the timed region: exactly K steps, nothing but the path's own launches on the stream (no per-launch events)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng.separate(L, R, out)
     sync()
     dt = time.perf_counter() - t0
+    # per-kernel durations: a second, separately timed pass of the same K steps with HIP events around every launch on the
+    # engine's own stream (what `roofline` and `kernel_ms` are computed from; its wall time is reported as ms_per_step_events)
+    eng.set_timing(True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.separate(L, R, out)
+    sync()
+    dt_ev = time.perf_counter() - t1
     tim = eng.get_timing()
     eng.set_timing(False)
     if world > 1:
@@ -182,7 +209,8 @@ def main():
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        frames_total = rows * world * a.steps
+        frames_step = int(eng.L.srtStftFrames(n))             # frames that actually get a transform (rows - 3: stftFix.c:378)
+        frames_total = frames_step * world * a.steps
         fps = frames_total / dt
         per = {}
         for name, ms in tim:
@@ -207,28 +235,45 @@ def main():
         dom_ms = sym_ms[dom] / sym_n[dom]
         dom_flop = sym_flop[dom] / sym_n[dom]
         dom_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
-        traffic = None
-        try:
-            pm = json.load(open(PMC_SUMMARY)).get(dom)
-            if pm and a.tiles == TILES:
-                traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic = mfma_busy = pmc_file = None
+        for pf in PMC_SUMMARIES:
+            try:
+                pm = json.load(open(pf)).get(dom)
+                if pm and a.tiles == TILES:
+                    traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
+                    # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs; 64 per v_mfma_f32_32x32x2_f32)
+                    # / (1024 x shader cycles of the launch = GRBM_GUI_ACTIVE / 8 XCDs), both from the profiled passes
+                    mfma_busy = pm.get("mfma_busy_frac")
+                    if mfma_busy is None and "sq" in pm and pm.get("effective_clock_ghz") and pm.get("sq_pass_avg_ns"):
+                        mfma_busy = pm["sq"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * pm["effective_clock_ghz"] * pm["sq_pass_avg_ns"])
+                    pmc_file = os.path.relpath(pf, ROOT)
+                    break
+            except Exception:
+                continue
+        step_ms = dt / a.steps * 1e3
         res = {
             "metric": "x_realtime (4-stem separation, 44.1 kHz stereo, PCM->stems resident in HBM); frames_per_s alongside",
             "value": fps * HOP / FS, "unit": "x real-time", "frames_per_s": fps,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "ms_per_step_events": dt_ev / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 products, f32 accumulate (conv only; STFT/iSTFT f32)", "f16x2": "f16x2 split products (exact in f32), f32 accumulate"}[a.precision],
             "data": "synthetic",
             "config": {"workload": "4-stem, fp32, batch=%d spectrogram tiles of %dx%d per GPU (BASELINE configs[2]); "
-                                   "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, rows, rows * HOP / FS),
+                                   "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, frames_step, frames_step * HOP / FS),
                        "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
                        "impl": a.impl, "precision": a.precision},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc.json)",
+                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, %s)" % pmc_file,
+                         "hbm_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                         "mfma_busy_frac": mfma_busy,
+                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the launch at the clock the chip held, GRBM_GUI_ACTIVE/8); frac is against the 2.4 GHz peak",
                          "flop_per_launch": dom_flop, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],
-                         "share_of_step": sym_ms[dom] / (dt / a.steps * 1e3)},
+                         "share_of_step": sym_ms[dom] / (dt_ev / a.steps * 1e3),
+                         # the whole path against the MFMA roofline: algorithmic network FLOP of one step / wall time of one step
+                         "step": {"achieved": nn_flop / (step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": nn_flop / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                  "note": "23 264 FLOP per T-F pixel per sub-net x pixels of the step / ms_per_step (STFT, iSTFT and launch gaps included in the time)"}},
             "nn_stack": {"achieved_tflops": nn_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "ms": nn_ms, "flop": nn_flop},
             # the HBM-bound stages against the same guide's 8 TB/s: algorithmic bytes per frame / measured kernel time

@@ -48,7 +48,9 @@ typedef struct srt_config {
     int   max_tiles;                /* capacity: tiles per batch */
     int   impl;                     /* SRT_IMPL_* */
     int   precision;                /* SRT_PREC_*: arithmetic of the conv contraction (accumulation and everything else is fp32) */
-    int   ratio_mask;               /* 0 (reference behaviour: raw sigmoid masks) | 1: srtSeparate* normalises m_s^2 / sum_j m_j^2 across stems (README.MD:82-85) */
+    int   ratio_mask;               /* 0 (reference behaviour: raw sigmoid masks) | 1: srtSeparate / srtSeparateEx / srtSeparateHostStream normalise
+                                     * m_s^2 / sum_j m_j^2 across stems (README.MD:82-85).  The CLI flows (srtSeparateCli*) reject it: their
+                                     * sub-networks run one after the other on different inputs, so there is no stem axis to normalise over. */
 } srt_config;
 
 SRT_API int  srtCreate(const srt_config *cfg, void *stream, srt_engine **out);
@@ -91,6 +93,11 @@ SRT_API int  srtSeparateEx(srt_engine *e, const float *d_L, const float *d_R, si
  * h_out: [n_stems][2][srtIstftLength(rows)].  Synchronous; replaces main()'s whole-file stft -> processMT -> istft
  * (Executable/main.c:776-785) for inputs of any length (the reference holds the full 4096-wide spectrogram in RAM). */
 SRT_API int  srtSeparateHostStream(srt_engine *e, const float *h_L, const float *h_R, size_t n, size_t frames, size_t rows, float *h_out);
+/* The same with flags.  SRT_HOST_PINNED: h_L, h_R and h_out are already page-locked (hipHostMalloc / hipHostRegister), so the
+ * call registers nothing (registering GBs of pageable memory per call costs more than the separation itself).  The device
+ * double buffers, copy streams and events are kept in the engine between calls either way. */
+#define SRT_HOST_PINNED 1u
+SRT_API int  srtSeparateHostStreamEx(srt_engine *e, const float *h_L, const float *h_R, size_t n, size_t frames, size_t rows, float *h_out, unsigned flags);
 
 /* The offline CLI's flows (Executable/main.c:776-798 for stems == 2, :845-928 for stems == 3), everything in HBM.
  * Sub-network 0 = the CLI's net[0] (drum, stem_mode 1), sub-network 1 = net[1] (vocal, stem_mode 0)  (main.c:759-760).

@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/{trace,pmc_*}: rocprofv3 kernel trace + stats of the default bench command, and separate
 # PMC passes (never combined with sys/hip/hsa tracing): SQ activity, HBM read bytes, HBM write bytes, clocks.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 
@@ -49,7 +49,7 @@ def pmc(sub):
 
 
 out = {}
-sq, sqn, _ = pmc("pmc_sq")
+sq, sqn, sqd = pmc("pmc_sq")
 fe, fen, _ = pmc("pmc_fetch")
 wr, wrn, _ = pmc("pmc_write")
 ck, ckn, ckd = pmc("pmc_clk")
@@ -67,6 +67,12 @@ for k in sorted(set(sq) | set(fe) | set(wr) | set(ck)):
         d["hbm_write_bytes_per_launch"] = wr[k]["WRITE_SIZE"] * 1024 / len(wrn[k])
     if k in ck and ckd[k] > 0:
         d["effective_clock_ghz"] = ck[k]["GRBM_GUI_ACTIVE"] / 8.0 / ckd[k]       # counter is summed over the 8 XCDs
+    if k in sq and sqd[k] > 0:
+        d["sq_pass_avg_ns"] = sqd[k] / len(sqn[k])
+        if "effective_clock_ghz" in d and sq[k].get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            # matrix-pipe busy fraction at the clock the chip held: busy cycles are summed over the 1024 SIMDs
+            # (64 per v_mfma_f32_32x32x2_f32); 1.0 = every SIMD's matrix pipe busy for the whole launch
+            d["mfma_busy_frac"] = sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * d["effective_clock_ghz"] * sqd[k])
     out[k] = d
 json.dump(out, open(os.path.join("profiles", tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 print("wrote profiles/%s_kernel_stats.csv and profiles/%s_pmc.json (%d kernels)" % (tag, tag, len(out)))

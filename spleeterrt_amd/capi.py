@@ -49,6 +49,7 @@ def load_library():
     L.srtSeparateCli.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_int, f32p]
     L.srtSeparateCliHost.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.srtSeparateHostStream.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    L.srtSeparateHostStreamEx.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_uint]
     for fn in (L.srtStftRows, L.srtStftFrames, L.srtIstftLength):
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_size_t]
@@ -187,20 +188,36 @@ class Engine:
         self._chk(self.L.srtSeparateCli(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, stems, _ptr(out)))
         return out
 
-    def separate_host_stream(self, L, R, frames=None, rows=None, out=None):
-        """host numpy PCM of any length -> host numpy stems [S,2,rows*1024+3072]; chunks of max_tiles tiles with the
-        PCIe copies overlapped with compute (srtSeparateHostStream)."""
+    def separate_host_stream(self, L, R, frames=None, rows=None, out=None, pinned=False):
+        """host PCM of any length -> host stems [S,2,rows*1024+3072]; chunks of max_tiles tiles with the PCIe copies
+        overlapped with compute (srtSeparateHostStreamEx).  L, R, out: contiguous float32 numpy arrays or CPU torch
+        tensors; pinned=True promises they are page-locked already (torch pin_memory), so nothing is registered per call."""
         import numpy as np
-        L = np.ascontiguousarray(L, np.float32)
-        R = np.ascontiguousarray(R, np.float32)
-        n = L.size
+
+        def host(a):
+            if hasattr(a, "data_ptr"):                           # CPU torch tensor (e.g. pin_memory=True)
+                assert not a.is_cuda and a.dtype == self.torch.float32 and a.is_contiguous()
+                return a, a.data_ptr(), a.numel()
+            a = np.ascontiguousarray(a, np.float32)
+            return a, a.ctypes.data, a.size
+        L, pL, n = host(L)
+        R, pR, nR = host(R)
+        assert n == nR
         rows = self.L.srtStftRows(n) if rows is None else rows
         frames = self.L.srtStftFrames(n) if frames is None else frames
+        shape = (self.S, 2, self.L.srtIstftLength(rows))
+        ret = None
         if out is None:
-            out = np.empty((self.S, 2, self.L.srtIstftLength(rows)), np.float32)
-        self._chk(self.L.srtSeparateHostStream(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), n, frames, rows,
-                                               C.c_void_p(out.ctypes.data)))
-        return out
+            if pinned:                                           # keep the promise for the output too
+                out = self.torch.empty(shape, dtype=self.torch.float32, pin_memory=True)
+                ret = out.numpy()
+            else:
+                out = np.empty(shape, np.float32)
+        out, pO, no = host(out)
+        assert no == shape[0] * shape[1] * shape[2]
+        self._chk(self.L.srtSeparateHostStreamEx(self.h, C.c_void_p(pL), C.c_void_p(pR), n, frames, rows, C.c_void_p(pO),
+                                                 1 if pinned else 0))
+        return out if ret is None else ret
 
     def separate_ex(self, L, R, frames, rows, out=None):
         """explicit-geometry form used by spleeterrt_amd.stream for tile ranges of a longer stream"""

@@ -45,6 +45,25 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
     const float v = srt_act_apply(acc + bias, a);                        // spleeter.c:244-245: activation BEFORE BN
     return scale * v + shift;
 }
+// Consumer-side form of the encoder's batch-norm + activation (spleeter.c:188): the producing layer stores conv + bias once
+// (the skip tensor) and the next encoder layer applies act(scale * v + shift) to the four staged values of one channel.
+// `ok` false = padding, which must stay exactly zero.  The ELU / non-ELU choice is workgroup-uniform (a scalar branch), so
+// LeakyReLU stems do not pay for a v_exp_f32 per staged value.  Same operations, same order as srt_enc_epilogue.
+__device__ __forceinline__ float srt_enc_input1(float v, float scale, float shift, const SrtAct& a)
+{
+    const float x = scale * v + shift;
+    if (a.ue != 0.0f) return srt_act_apply(x, a);
+    return x >= 0.0f ? x : a.lin * x;
+}
+__device__ __forceinline__ float4 srt_enc_input4(float4 v, float scale, float shift, bool ok, const SrtAct& a)
+{
+    float4 o;
+    o.x = ok ? srt_enc_input1(v.x, scale, shift, a) : 0.0f;
+    o.y = ok ? srt_enc_input1(v.y, scale, shift, a) : 0.0f;
+    o.z = ok ? srt_enc_input1(v.z, scale, shift, a) : 0.0f;
+    o.w = ok ? srt_enc_input1(v.w, scale, shift, a) : 0.0f;
+    return o;
+}
 // branchy forms (naive cross-check kernels)
 __device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, int act, int variant)
 {

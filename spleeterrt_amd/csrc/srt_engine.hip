@@ -3,8 +3,8 @@
 // HBM layout (all fp32, instance = (stem, tile), CHW planar, row = time, contiguous = frequency):
 //   coeff[stem]           raw spleeterCoeff blob (Executable/spleeter.h:5-31), biases / BN read in place
 //   wpack[stem][layer]    GEMM-ready weights [Cin][25][CP]
-//   raw[i]  i=0..5        encoder conv+bias outputs (the skip tensors)   [stem][tile][Cout][H>>i+1][W>>i+1]
-//   act[i]  i=0..4        BN+activation copies feeding the next encoder layer
+//   raw[i]  i=0..5        encoder conv+bias outputs   [stem][tile][Cout][H>>i+1][W>>i+1]: the skip tensors AND the next encoder
+//                         layer's input (its BN + activation is applied by the consumer while staging; nothing is stored twice)
 //   up[i]   i=0..5        decoder outputs (new channels only; the concat is done by pointer)
 //   spec / mag / masks / frames / pcm for the DSP stages
 #include "srt_internal.h"
@@ -17,11 +17,12 @@
 #include <vector>
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, const char* detail = "")
+int srt_set_error(int code, const char* fmt, const char* detail)      // shared with the drop-in layers (srt_compat.hip, srt_stream.hip)
 {
     snprintf(g_err, sizeof g_err, fmt, detail);
     return code;
 }
+static int fail(int code, const char* fmt, const char* detail = "") { return srt_set_error(code, fmt, detail); }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(-2, "HIP error: %s", hipGetErrorString(_e)); } while (0)
 
 static const int ENC_CH[6][2] = { {2, 16}, {16, 32}, {32, 64}, {64, 128}, {128, 256}, {256, 512} };
@@ -46,10 +47,33 @@ static Layout make_layout()
 }
 
 struct TimingEntry { std::string name; hipEvent_t a, b; };
+#define SRT_TIMING_MAX 65536        // launches recorded per srtSetTiming(1) window; later launches run untimed
+
+// Persistent staging of srtSeparateHostStream / srtSeparateCliHost: device double buffers, copy streams and events are
+// created on first use, grown when a call needs more, and freed with the engine (not allocated per call).
+struct HostStaging {
+    float* d_in[2]; float* d_out[2]; float* d_carry;
+    size_t in_cap, out_cap, carry_cap;                 // floats
+    hipStream_t s_in, s_out;
+    hipEvent_t ev_in[2], ev_cmp[2], ev_out[2];
+    bool ready;
+};
+
+// Every entry point that allocates or launches runs on the device the engine was created on, whatever the caller's
+// current device is (a host thread that switched devices after srtCreate must not mix device-A streams with device-B memory).
+struct DeviceScope {
+    int prev; bool sw;
+    explicit DeviceScope(int dev) : prev(-1), sw(false) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) sw = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (sw) hipSetDevice(prev); }
+};
 
 struct srt_engine {
     srt_config cfg;
+    int device;
     hipStream_t stream;
+    HostStaging hs;
     Layout lo;
     float* coeff_all;                                  // [n_stems][SRT_COEFF_STRIDE]
     float* wpack_down[6]; float* wpack_up[6];          // per layer: [n_stems][Cin*25*CP]
@@ -59,8 +83,8 @@ struct srt_engine {
     float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     bool   have_coeff[SRT_MAX_STEMS];
-    float* raw[6]; float* act[5]; float* up[6];
-    size_t raw_tile[6], act_tile[5], up_tile[6];       // floats per instance
+    float* raw[6]; float* up[6];
+    size_t raw_tile[6], up_tile[6];                    // floats per instance
     // DSP
     float *preWin, *postWin; float2* twiddle;
     float2* spec; float2* spec2; float* mag; float* masks; float* frames;   // spec2: residual spectrum of the CLI chain (on first use)
@@ -78,24 +102,42 @@ size_t srtIstftLength(size_t rows) { return rows * SRT_HOP + (SRT_FFT - SRT_HOP)
 
 struct TimerScope {
     srt_engine* e; size_t idx; bool on;
-    TimerScope(srt_engine* e_, const char* name) : e(e_), idx(0), on(e_->timing) {
+    TimerScope(srt_engine* e_, const char* name) : e(e_), idx(0), on(e_->timing && e_->tlog.size() < SRT_TIMING_MAX) {
         if (!on) return;
         TimingEntry t; t.name = name;
-        hipEventCreate(&t.a); hipEventCreate(&t.b);
+        if (hipEventCreate(&t.a) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&t.b) != hipSuccess) { hipEventDestroy(t.a); on = false; return; }
         hipEventRecord(t.a, e->stream);
         e->tlog.push_back(t); idx = e->tlog.size() - 1;
     }
     ~TimerScope() { if (on) hipEventRecord(e->tlog[idx].b, e->stream); }
 };
 
+static void free_staging(srt_engine* e)
+{
+    HostStaging& h = e->hs;
+    for (int b = 0; b < 2; ++b) {
+        if (h.d_in[b]) hipFree(h.d_in[b]);
+        if (h.d_out[b]) hipFree(h.d_out[b]);
+        if (h.ev_in[b]) hipEventDestroy(h.ev_in[b]);
+        if (h.ev_cmp[b]) hipEventDestroy(h.ev_cmp[b]);
+        if (h.ev_out[b]) hipEventDestroy(h.ev_out[b]);
+    }
+    if (h.d_carry) hipFree(h.d_carry);
+    if (h.s_in) hipStreamDestroy(h.s_in);
+    if (h.s_out) hipStreamDestroy(h.s_out);
+    memset(&h, 0, sizeof h);
+}
+
 static void free_all(srt_engine* e)
 {
+    free_staging(e);
     if (e->coeff_all) hipFree(e->coeff_all);
     for (int i = 0; i < 6; ++i) { if (e->wpack16_down[i]) hipFree(e->wpack16_down[i]); if (e->wpack16_up[i]) hipFree(e->wpack16_up[i]); }
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
-    for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act[i]) hipFree(e->act[i]); }
+    for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); }
     void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->spec2, e->mag, e->masks, e->frames };
     for (void* m : misc) if (m) hipFree(m);
     for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -110,10 +152,12 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "srtCreate: no HIP device (this library has no CPU path)");
     srt_engine* e = new srt_engine();
+    memset(&e->hs, 0, sizeof e->hs);
+    if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail(-3, "srtCreate: no current HIP device"); }
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
-    memset(e->raw, 0, sizeof e->raw); memset(e->act, 0, sizeof e->act); memset(e->up, 0, sizeof e->up);
+    memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up);
     e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->spec2 = nullptr; e->mag = e->masks = e->frames = nullptr;
     e->cfg = *cfg; e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
     if (e->lo.total != SRT_COEFF_FLOATS) { delete e; return fail(-4, "internal: weight layout size mismatch"); }
@@ -140,7 +184,6 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     for (int i = 0; i < 6; ++i) {
         e->raw_tile[i] = (size_t)ENC_CH[i][1] * (HW >> (2 * (i + 1)));
         EALLOC(e->raw[i], S * NT * e->raw_tile[i]);
-        if (i < 5) { e->act_tile[i] = e->raw_tile[i]; EALLOC(e->act[i], S * NT * e->act_tile[i]); }
         e->up_tile[i] = (size_t)DEC_CH[i][1] * (HW >> (2 * (5 - i)));
         EALLOC(e->up[i], S * NT * e->up_tile[i]);
     }
@@ -175,6 +218,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
 void srtDestroy(srt_engine* e)
 {
     if (!e) return;
+    DeviceScope ds(e->device);
     hipStreamSynchronize(e->stream);
     free_all(e);
     delete e;
@@ -199,6 +243,7 @@ static int pack_stem(srt_engine* e, int stem)
 int srtSetCoeffHost(srt_engine* e, int stem, const void* h)
 {
     if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffHost: bad argument");
+    DeviceScope ds(e->device);
     HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, h, srtCoeffBytes(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return pack_stem(e, stem);
@@ -206,12 +251,14 @@ int srtSetCoeffHost(srt_engine* e, int stem, const void* h)
 int srtSetCoeffDevice(srt_engine* e, int stem, const void* d)
 {
     if (!e || !d || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffDevice: bad argument");
+    DeviceScope ds(e->device);
     HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, d, srtCoeffBytes(), hipMemcpyDeviceToDevice, e->stream));
     return pack_stem(e, stem);
 }
 int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 {
     if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffFp16Host: bad argument");
+    DeviceScope ds(e->device);
     uint16_t* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)SRT_COEFF_FLOATS * 2));
     hipError_t er = hipMemcpyAsync(d, h, (size_t)SRT_COEFF_FLOATS * 2, hipMemcpyHostToDevice, e->stream);
@@ -227,6 +274,7 @@ int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int s0, int ns)
 {
     if (!e || !d_mag || !d_masks) return fail(-1, "srtForward: null argument");
+    DeviceScope ds(e->device);
     if (ntiles < 1 || ntiles > e->cfg.max_tiles) return fail(-1, "srtForward: ntiles exceeds max_tiles");
     const int S = e->cfg.n_stems, T = e->cfg.T, F = e->cfg.F;
     if (s0 < 0 || ns < 1 || s0 + ns > S) return fail(-1, "srtForward: stem range outside the engine's sub-networks");
@@ -245,14 +293,18 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             SrtConvParams p; memset(&p, 0, sizeof p);
             p.Cin = L.cin; p.Cout = L.cout; p.H = T >> i; p.W = F >> i; p.CA = L.cin; p.ntiles = ntiles; p.nstems = ns;
             if (i == 0) { p.srcA = d_mag; p.srcA_stem = 0; p.srcA_tile = 2 * HW; }                 // every stem reads the same magnitudes
-            else { p.srcA = e->act[i - 1] + (size_t)s0 * ntiles * e->act_tile[i - 1]; p.srcA_stem = (size_t)ntiles * e->act_tile[i - 1]; p.srcA_tile = e->act_tile[i - 1]; }
+            else {
+                // the previous layer's conv + bias; its batch-norm + activation (spleeter.c:188) is applied by this layer while staging
+                const LayerOff& P = e->lo.down[i - 1];
+                p.srcA = e->raw[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1]; p.srcA_stem = (size_t)ntiles * e->raw_tile[i - 1]; p.srcA_tile = e->raw_tile[i - 1];
+                p.inShift = cbase + P.bn; p.inScale = cbase + P.bn + P.cout;
+            }
             p.srcB = p.srcA;
-            p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = i < 5 ? cbase + L.bn : nullptr; p.bnScale = i < 5 ? cbase + L.bn + L.cout : nullptr;
+            p.wraw = cbase + L.w; p.bias = cbase + L.b;
             p.coeff_stem = SRT_COEFF_STRIDE;
             p.wpack = e->wpack_down[i] + (size_t)s0 * e->wpack_down_stem[i]; p.wpack_stem = e->wpack_down_stem[i];
             p.CP = L.cp;
             p.outRaw = e->raw[i] + (size_t)s0 * ntiles * e->raw_tile[i];
-            p.outAct = i < 5 ? e->act[i] + (size_t)s0 * ntiles * e->act_tile[i] : nullptr;
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
@@ -332,6 +384,7 @@ int srtForwardStems(srt_engine* e, const float* d_mag, int ntiles, float* d_mask
 int srtRatioMask(srt_engine* e, float* d_masks, int ntiles)
 {
     if (!e || !d_masks || ntiles < 1) return fail(-1, "srtRatioMask: bad argument");
+    DeviceScope ds(e->device);
     TimerScope ts(e, "ratio");
     if (srt_launch_ratio_mask(d_masks, e->cfg.n_stems, (size_t)ntiles * 2 * e->cfg.T * e->cfg.F, e->stream)) return fail(-2, "ratio-mask launch failed");
     return 0;
@@ -342,6 +395,7 @@ static SrtDspTables tables_of(const srt_engine* e) { SrtDspTables t; t.preWin = 
 int srtStftEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_spec, float* d_mag)
 {
     if (!e || !d_L || !d_R || !d_spec) return fail(-1, "srtStft: null argument");
+    DeviceScope ds(e->device);
     if (rows < 1 || frames > rows) return fail(-1, "srtStft: need 1 <= frames <= rows");
     const int T = e->cfg.T;
     const size_t ntiles = (rows + T - 1) / T;
@@ -371,6 +425,7 @@ int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* 
 int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out)
 {
     if (!e || !d_spec || !d_out) return fail(-1, "srtIstft: null argument");
+    DeviceScope ds(e->device);
     if (rows < 1) return fail(-1, "srtIstft: no rows");
     const int T = e->cfg.T;
     if (d_masks && (rows + T - 1) / T > (size_t)e->cfg.max_tiles) return fail(-1, "srtIstft: rows exceed max_tiles * T");
@@ -402,6 +457,7 @@ int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, s
 // iSTFT of one spectrum under ONE stem's mask (or none) into a [2][len] destination
 static int istft_one(srt_engine* e, const float2* spec, size_t rows, const float* mask_stem, float oob, float* d_dst, const char* tag)
 {
+    DeviceScope ds(e->device);
     const int T = e->cfg.T;
     SrtIstftParams p; memset(&p, 0, sizeof p);
     p.spec = spec; p.spec_ch_stride = rows * SRT_SPEC_LD;
@@ -421,8 +477,10 @@ static int istft_one(srt_engine* e, const float2* spec, size_t rows, const float
 int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out)
 {
     if (!e || !d_L || !d_R || !d_out) return fail(-1, "srtSeparateCli: null argument");
+    DeviceScope ds(e->device);
     if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
     if (e->cfg.n_stems < 2) return fail(-1, "srtSeparateCli: the engine needs sub-networks 0 (drum) and 1 (vocal)");
+    if (e->cfg.ratio_mask) return fail(-1, "srtSeparateCli: ratio_mask does not apply to the CLI flows (the sub-networks see different inputs)");
     if (n < SRT_FFT) return fail(-1, "srtSeparateCli: need at least 4096 samples");
     const int T = e->cfg.T;
     const size_t rows = srtStftRows(n), frames = srtStftFrames(n), ntiles = (rows + T - 1) / T, len = srtIstftLength(rows);
@@ -457,25 +515,64 @@ int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, 
     return 0;
 }
 
+// Grow-only device staging shared by the host-buffer entry points (kept in the engine, freed by srtDestroy).
+static int ensure_staging(srt_engine* e, size_t in_floats, size_t out_floats, size_t carry_floats, int nbuf)
+{
+    HostStaging& h = e->hs;
+    if (!h.ready) {
+        HIPCHK(hipStreamCreateWithFlags(&h.s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h.s_out, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipEventCreateWithFlags(&h.ev_in[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h.ev_cmp[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h.ev_out[b], hipEventDisableTiming));
+        }
+        h.ready = true;
+    }
+    if (in_floats > h.in_cap || out_floats > h.out_cap || carry_floats > h.carry_cap) {
+        // buffers may still be in use by an earlier call's asynchronous work: drain before replacing them
+        HIPCHK(hipStreamSynchronize(h.s_in)); HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipStreamSynchronize(h.s_out));
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (in_floats > h.in_cap || (b < nbuf && !h.d_in[b])) {
+            if (h.d_in[b]) { hipFree(h.d_in[b]); h.d_in[b] = nullptr; }
+            if (b < nbuf) HIPCHK(hipMalloc((void**)&h.d_in[b], (in_floats > h.in_cap ? in_floats : h.in_cap) * sizeof(float)));
+        }
+        if (out_floats > h.out_cap || (b < nbuf && !h.d_out[b])) {
+            if (h.d_out[b]) { hipFree(h.d_out[b]); h.d_out[b] = nullptr; }
+            if (b < nbuf) HIPCHK(hipMalloc((void**)&h.d_out[b], (out_floats > h.out_cap ? out_floats : h.out_cap) * sizeof(float)));
+        }
+    }
+    if (in_floats > h.in_cap) h.in_cap = in_floats;
+    if (out_floats > h.out_cap) h.out_cap = out_floats;
+    if (carry_floats > h.carry_cap) {
+        if (h.d_carry) { hipFree(h.d_carry); h.d_carry = nullptr; }
+        HIPCHK(hipMalloc((void**)&h.d_carry, carry_floats * sizeof(float)));
+        h.carry_cap = carry_floats;
+    }
+    return 0;
+}
+
 // Host-buffer convenience over srtSeparateCli for plain-C callers (the CLI harness): H2D, chain, D2H, synchronous.
+// The device copies of the input and the outputs live in the engine's staging buffers (grown on demand, reused by later calls).
 int srtSeparateCliHost(srt_engine* e, const float* h_L, const float* h_R, size_t n, int stems, float* h_out)
 {
     if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateCliHost: null argument");
     if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
+    DeviceScope ds(e->device);
     const size_t len = srtIstftLength(srtStftRows(n));
-    float *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_in, 2 * n * sizeof(float)));
-    if (hipMalloc((void**)&d_out, (size_t)stems * 2 * len * sizeof(float)) != hipSuccess) { hipFree(d_in); return fail(-2, "srtSeparateCliHost: hipMalloc failed"); }
+    int rc = ensure_staging(e, 2 * n, (size_t)stems * 2 * len, 0, 1);
+    if (rc) return rc;
+    float *d_in = e->hs.d_in[0], *d_out = e->hs.d_out[0];
     hipError_t er = hipMemcpyAsync(d_in, h_L, n * sizeof(float), hipMemcpyHostToDevice, e->stream);
     if (er == hipSuccess) er = hipMemcpyAsync(d_in + n, h_R, n * sizeof(float), hipMemcpyHostToDevice, e->stream);
-    int rc = er == hipSuccess ? srtSeparateCli(e, d_in, d_in + n, n, stems, d_out) : fail(-2, "HIP error: %s", hipGetErrorString(er));
+    rc = er == hipSuccess ? srtSeparateCli(e, d_in, d_in + n, n, stems, d_out) : fail(-2, "HIP error: %s", hipGetErrorString(er));
     if (!rc) {
         er = hipMemcpyAsync(h_out, d_out, (size_t)stems * 2 * len * sizeof(float), hipMemcpyDeviceToHost, e->stream);
         if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
         if (er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
     }
     hipStreamSynchronize(e->stream);
-    hipFree(d_in); hipFree(d_out);
     return rc;
 }
 
@@ -490,35 +587,30 @@ int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, flo
 // and the 3072-sample overlap between consecutive chunks is added on the device (srt_carry_kernel), so every output
 // sample crosses PCIe exactly once.  Geometry as srtSeparateEx (a tile range of a longer stream: rows = whole tiles,
 // frames = rows; the whole stream: rows = srtStftRows(n), frames = srtStftFrames(n)).
-int srtSeparateHostStream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out)
+int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags)
 {
     if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateHostStream: null argument");
     if (rows < 1 || frames > rows) return fail(-1, "srtSeparateHostStream: need 1 <= frames <= rows");
+    DeviceScope ds(e->device);
     const int S = e->cfg.n_stems, T = e->cfg.T, NP = S * 2;
     const size_t chunk_rows = (size_t)e->cfg.max_tiles * T, tail = SRT_FFT - SRT_HOP;
     const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows, total_len = srtIstftLength(rows);
     const size_t in_cap = chunk_rows * SRT_HOP + tail, out_cap = srtIstftLength(chunk_rows);
-    float *d_in[2] = { nullptr, nullptr }, *d_out[2] = { nullptr, nullptr }, *d_carry = nullptr;
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_cmp[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
-    // pinning the caller's buffers lets the copies run asynchronously; if the pages are already pinned (or cannot be), carry on
-    const bool pinL = hipHostRegister((void*)h_L, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
-    const bool pinR = hipHostRegister((void*)h_R, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
-    const bool pinO = hipHostRegister((void*)h_out, (size_t)NP * total_len * sizeof(float), hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-    int rc = 0;
+    int rc = ensure_staging(e, 2 * in_cap, (size_t)NP * out_cap, (size_t)NP * tail, 2);
+    if (rc) return rc;
+    HostStaging& h = e->hs;
+    // Page-locked caller buffers let the copies run asynchronously.  SRT_HOST_PINNED: the caller guarantees they already are
+    // (hipHostMalloc / hipHostRegister / torch pin_memory) and nothing is registered here; otherwise the three buffers are
+    // registered for the duration of the call (if that fails the copies still work, staged by the runtime).
+    bool pinL = false, pinR = false, pinO = false;
+    if (!(flags & SRT_HOST_PINNED)) {
+        pinL = hipHostRegister((void*)h_L, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+        pinR = hipHostRegister((void*)h_R, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+        pinO = hipHostRegister((void*)h_out, (size_t)NP * total_len * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
     hipError_t er = hipSuccess;
 #define STEP(x) do { if (er == hipSuccess) er = (x); } while (0)
-    for (int b = 0; b < 2; ++b) {
-        STEP(hipMalloc((void**)&d_in[b], 2 * in_cap * sizeof(float)));
-        STEP(hipMalloc((void**)&d_out[b], (size_t)NP * out_cap * sizeof(float)));
-        STEP(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
-        STEP(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming));
-        STEP(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
-    }
-    STEP(hipMalloc((void**)&d_carry, (size_t)NP * tail * sizeof(float)));
-    STEP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
-    STEP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
     for (size_t c = 0; c < nchunks && er == hipSuccess && rc == 0; ++c) {
         const int b = (int)(c & 1);
         const size_t row0 = c * chunk_rows, row1 = row0 + chunk_rows < rows ? row0 + chunk_rows : rows, crow = row1 - row0;
@@ -527,66 +619,77 @@ int srtSeparateHostStream(srt_engine* e, const float* h_L, const float* h_R, siz
         const size_t cfr = frames > row0 ? (frames - row0 < crow ? frames - row0 : crow) : 0;
         const size_t clen = srtIstftLength(crow);
         // upload: the input buffer is free once the compute that read it two chunks ago has finished
-        if (c >= 2) STEP(hipStreamWaitEvent(s_in, ev_cmp[b], 0));
+        if (c >= 2) STEP(hipStreamWaitEvent(h.s_in, h.ev_cmp[b], 0));
         if (ns) {
-            STEP(hipMemcpyAsync(d_in[b], h_L + s0, ns * sizeof(float), hipMemcpyHostToDevice, s_in));
-            STEP(hipMemcpyAsync(d_in[b] + in_cap, h_R + s0, ns * sizeof(float), hipMemcpyHostToDevice, s_in));
+            STEP(hipMemcpyAsync(h.d_in[b], h_L + s0, ns * sizeof(float), hipMemcpyHostToDevice, h.s_in));
+            STEP(hipMemcpyAsync(h.d_in[b] + in_cap, h_R + s0, ns * sizeof(float), hipMemcpyHostToDevice, h.s_in));
         }
-        STEP(hipEventRecord(ev_in[b], s_in));
+        STEP(hipEventRecord(h.ev_in[b], h.s_in));
         // compute: needs this chunk's PCM and the output buffer drained by the download of two chunks ago
-        STEP(hipStreamWaitEvent(e->stream, ev_in[b], 0));
-        if (c >= 2) STEP(hipStreamWaitEvent(e->stream, ev_out[b], 0));
+        STEP(hipStreamWaitEvent(e->stream, h.ev_in[b], 0));
+        if (c >= 2) STEP(hipStreamWaitEvent(e->stream, h.ev_out[b], 0));
         if (er != hipSuccess) break;
-        rc = srtSeparateEx(e, d_in[b], d_in[b] + in_cap, ns, cfr, crow, d_out[b]);
+        rc = srtSeparateEx(e, h.d_in[b], h.d_in[b] + in_cap, ns, cfr, crow, h.d_out[b]);
         if (rc) break;
-        if (srt_launch_carry(d_out[b], clen, NP, crow * SRT_HOP, d_carry, c == 0, c + 1 == nchunks, e->stream)) { rc = fail(-2, "carry launch failed"); break; }
-        STEP(hipEventRecord(ev_cmp[b], e->stream));
+        if (srt_launch_carry(h.d_out[b], clen, NP, crow * SRT_HOP, h.d_carry, c == 0, c + 1 == nchunks, e->stream)) { rc = fail(-2, "carry launch failed"); break; }
+        STEP(hipEventRecord(h.ev_cmp[b], e->stream));
         // download: every plane's [0, crow*1024) (+ the final 3072 on the last chunk) lands at its place in h_out
-        STEP(hipStreamWaitEvent(s_out, ev_cmp[b], 0));
+        STEP(hipStreamWaitEvent(h.s_out, h.ev_cmp[b], 0));
         const size_t take = c + 1 == nchunks ? clen : crow * SRT_HOP;
-        STEP(hipMemcpy2DAsync(h_out + s0, total_len * sizeof(float), d_out[b], clen * sizeof(float), take * sizeof(float), NP, hipMemcpyDeviceToHost, s_out));
-        STEP(hipEventRecord(ev_out[b], s_out));
+        STEP(hipMemcpy2DAsync(h_out + s0, total_len * sizeof(float), h.d_out[b], clen * sizeof(float), take * sizeof(float), NP, hipMemcpyDeviceToHost, h.s_out));
+        STEP(hipEventRecord(h.ev_out[b], h.s_out));
     }
 #undef STEP
-    if (s_in) hipStreamSynchronize(s_in);
+    hipStreamSynchronize(h.s_in);
     hipStreamSynchronize(e->stream);
-    if (s_out) hipStreamSynchronize(s_out);
+    hipStreamSynchronize(h.s_out);
     if (rc == 0 && er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
-    for (int b = 0; b < 2; ++b) {
-        if (d_in[b]) hipFree(d_in[b]);
-        if (d_out[b]) hipFree(d_out[b]);
-        if (ev_in[b]) hipEventDestroy(ev_in[b]);
-        if (ev_cmp[b]) hipEventDestroy(ev_cmp[b]);
-        if (ev_out[b]) hipEventDestroy(ev_out[b]);
-    }
-    if (d_carry) hipFree(d_carry);
-    if (s_in) hipStreamDestroy(s_in);
-    if (s_out) hipStreamDestroy(s_out);
     if (pinL) hipHostUnregister((void*)h_L);
     if (pinR) hipHostUnregister((void*)h_R);
     if (pinO) hipHostUnregister((void*)h_out);
     return rc;
 }
 
+int srtSeparateHostStream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out)
+{
+    return srtSeparateHostStreamEx(e, h_L, h_R, n, frames, rows, h_out, 0);
+}
+
 int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_dst, size_t max_floats)
 {
     if (!e || !name || !h_dst) return fail(-1, "srtCopyTensor: null argument");
+    DeviceScope ds(e->device);
+    if (!name[0]) return fail(-1, "srtCopyTensor: empty tensor name");
+    if (stem < 0 || stem >= e->cfg.n_stems || tile < 0 || tile >= e->last_ntiles) return fail(-1, "srtCopyTensor: stem / tile outside the last forward batch");
     const int idx = name[strlen(name) - 1] - '1';
-    const float* base = nullptr; size_t per = 0;
+    const float* base = nullptr; size_t per = 0; bool derived = false;
     if (!strncmp(name, "conv", 4) && idx >= 0 && idx < 6) { base = e->raw[idx]; per = e->raw_tile[idx]; }
-    else if (!strncmp(name, "act", 3) && idx >= 0 && idx < 5) { base = e->act[idx]; per = e->act_tile[idx]; }
+    else if (!strncmp(name, "act", 3) && idx >= 0 && idx < 5) { base = e->raw[idx]; per = e->raw_tile[idx]; derived = true; }
     else if (!strncmp(name, "up", 2) && idx >= 0 && idx < 6) { base = e->up[idx]; per = e->up_tile[idx]; }
     else return fail(-1, "srtCopyTensor: unknown tensor %s", name);
     if (per > max_floats) return fail(-1, "srtCopyTensor: destination too small");
     // instance stride = ntiles of the last srtForward call
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(h_dst, base + ((size_t)stem * e->last_ntiles + tile) * per, per * sizeof(float), hipMemcpyDeviceToHost));
-    return (int)0;
+    const float* src = base + ((size_t)stem * e->last_ntiles + tile) * per;
+    float* tmp = nullptr;
+    if (derived) {
+        // "actN" is no longer stored: the next encoder layer applies act(bn(convN)) while staging.  Materialise it for the tap.
+        const LayerOff& L = e->lo.down[idx];
+        const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
+        HIPCHK(hipMalloc((void**)&tmp, per * sizeof(float)));
+        if (srt_launch_bn_act(src, tmp, c + L.bn + L.cout, c + L.bn, L.cout, per / L.cout, e->cfg.stem_mode[stem] ? SRT_ACT_ELU : SRT_ACT_LEAKY, e->cfg.variant, e->stream)) { hipFree(tmp); return fail(-2, "bn-act launch failed"); }
+        src = tmp;
+    }
+    hipError_t er = hipStreamSynchronize(e->stream);
+    if (er == hipSuccess) er = hipMemcpy(h_dst, src, per * sizeof(float), hipMemcpyDeviceToHost);
+    if (tmp) hipFree(tmp);
+    HIPCHK(er);
+    return 0;
 }
 
 int srtSetTiming(srt_engine* e, int enable)
 {
     if (!e) return fail(-1, "null engine");
+    DeviceScope ds(e->device);
     for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     e->tlog.clear();
     e->timing = enable != 0;
@@ -595,7 +698,8 @@ int srtSetTiming(srt_engine* e, int enable)
 
 int srtGetTiming(srt_engine* e, char* names, size_t names_bytes, float* ms, int max_entries)
 {
-    if (!e) return fail(-1, "null engine");
+    if (!e || !ms || max_entries < 0) return fail(-1, "srtGetTiming: bad argument");
+    DeviceScope ds(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     int n = 0; size_t used = 0;
     if (names && names_bytes) names[0] = 0;

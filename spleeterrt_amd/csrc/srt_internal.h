@@ -11,7 +11,11 @@
 #define SRT_HALF 2049
 #define SRT_SPEC_LD 2052          // float2 elements per spectrum row (2049 padded to a 16-byte multiple)
 #define SRT_COEFF_FLOATS 9822725u // sizeof(spleeterCoeff)/4, Executable/spleeter.h:5-31
+#define SRT_ENC_MAX_CIN 256       // widest encoder input (down6)
 #define SRT_COEFF_STRIDE 9822784u // per-stem stride inside the engine's single weight allocation (64-float aligned)
+
+// error text behind srtLastError() (thread-local), settable from every translation unit of the library; returns `code`
+int srt_set_error(int code, const char* fmt, const char* detail);
 
 enum { SRT_ACT_LEAKY = 0, SRT_ACT_RELU = 1, SRT_ACT_ELU = 2 };
 
@@ -24,6 +28,10 @@ struct SrtConvParams {
     int ntiles, nstems;
     const float* srcA; size_t srcA_stem, srcA_tile;
     const float* srcB; size_t srcB_stem, srcB_tile;
+    // Encoder layers 2..6 read the RAW (conv + bias) tensor of the previous layer and apply its batch-norm + activation
+    // while staging: x = act(inScale[c] * raw + inShift[c]) (spleeter.c:188), per input channel c and per stem
+    // (pointer = base + stem * coeff_stem + c).  nullptr: the source is used as it is (down1 reads magnitudes).
+    const float* inScale; const float* inShift;
     // per-stem weights: pointer = base + stem * stride (all stems live in one allocation, so no pointer tables)
     const float* wraw;    // reference layout: encoder OIHW [Cout][Cin][5][5], decoder [Cin][Cout][5][5]
     const float* bias; const float* bnShift; const float* bnScale;   // bnScale == nullptr => no batch-norm (down6)
@@ -39,8 +47,8 @@ struct SrtConvParams {
     // fp16-MFMA variant (srt_nn3.hip): [Cin/16][25][2][CP][8] IEEE halves (k-group of 8 channels innermost)
     const uint16_t* wpack16; size_t wpack16_stem;
     int nsplit;           // 1: activations rounded to fp16; 2: activations split hi+lo (two MFMAs per tap, ~fp32 products)
-    float* outRaw;        // encoder: conv+bias (skip tensor); decoder: unused
-    float* outAct;        // encoder: act(bn(v)); decoder: bn(act(v))
+    float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
+    float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)
     size_t out_stem, out_tile;
     int act;              // activation kind of the stems whose elu_mask bit is clear (encoder: LeakyReLU, decoder: ReLU)
     unsigned elu_mask;    // bit s set: stem s of this launch uses ELU (stemMode != 0, spleeter.c:130-139)
@@ -59,6 +67,7 @@ struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sig
 int  srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_head(const SrtHeadParams& p, hipStream_t s);
+int  srt_launch_bn_act(const float* raw, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s);
 int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 // v2 kernels (srt_nn2.hip): return 1 when the layer geometry is not covered (caller falls back to the v1 kernels)

@@ -50,6 +50,8 @@ __global__ void srt_enc_naive(const SrtConvParams p)
     const int stem = blockIdx.y / p.ntiles, tile = blockIdx.y % p.ntiles;
     const size_t hw = (size_t)p.H * p.W, total = (size_t)p.Cout * Ho * Wo;
     const float* w = p.wraw + stem * p.coeff_stem;
+    const size_t cs = stem * p.coeff_stem;
+    const int kind = srt_act_kind(p, stem);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int ox = e % Wo, oy = (e / Wo) % Ho, co = e / ((size_t)Wo * Ho);
         float acc = 0.0f;
@@ -61,15 +63,14 @@ __global__ void srt_enc_naive(const SrtConvParams p)
                 if (r < 0 || r >= p.H) continue;
                 for (int kx = 0; kx < 5; ++kx) {
                     const int c = 2 * ox + kx - 1;
-                    if (c >= 0 && c < p.W) acc += wk[ky * 5 + kx] * x[(size_t)r * p.W + c];
+                    if (c < 0 || c >= p.W) continue;
+                    float xv = x[(size_t)r * p.W + c];
+                    if (p.inScale) xv = srt_enc_epilogue(xv, p.inScale[cs + ci], p.inShift[cs + ci], kind, p.variant);   // producer stored conv + bias only
+                    acc += wk[ky * 5 + kx] * xv;
                 }
             }
         }
-        const size_t cs = stem * p.coeff_stem;
-        const float v = acc + p.bias[cs + co];
-        const size_t o = stem * p.out_stem + tile * p.out_tile + e;
-        p.outRaw[o] = v;
-        if (p.bnScale) p.outAct[o] = srt_enc_epilogue(v, p.bnScale[cs + co], p.bnShift[cs + co], srt_act_kind(p, stem), p.variant);
+        p.outRaw[stem * p.out_stem + tile * p.out_tile + e] = acc + p.bias[cs + co];
     }
 }
 
@@ -97,6 +98,22 @@ __global__ void srt_dec_naive(const SrtConvParams p)
         p.outAct[stem * p.out_stem + tile * p.out_tile + e] =
             srt_dec_epilogue(acc, p.bias[stem * p.coeff_stem + co], p.bnScale[stem * p.coeff_stem + co], p.bnShift[stem * p.coeff_stem + co], srt_act_kind(p, stem), p.variant);
     }
+}
+
+// act(bn(raw)) of one instance into a scratch tensor: what the next encoder layer applies while staging, materialised only
+// for srtCopyTensor("actN") (debug / parity taps)
+__global__ void srt_bn_act_kernel(const float* __restrict__ raw, float* __restrict__ out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant)
+{
+    const size_t total = (size_t)C * hw;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / hw);
+        out[e] = srt_enc_epilogue(raw[e], scale[c], shift[c], kind, variant);
+    }
+}
+int srt_launch_bn_act(const float* raw, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, out, scale, shift, C, hw, kind, variant);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // up7 head: direct 16-tap stencil, both output channels per thread (bandwidth kernel; 1 MiB in, 2 MiB out per instance)
@@ -287,7 +304,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
             const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 + col - 1, tile = tile0 + il;
             const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const float* src = srt_src_channel(p, stem, ok ? tile : tile0, c0 + c, hw);
-            const float v = src[ok ? (size_t)gy * p.W + gx : 0];
+            float v = src[ok ? (size_t)gy * p.W + gx : 0];
+            // fallback kernel (widths that are not multiples of 4): the producer's BN + activation is applied right at the load
+            if (p.inScale) v = srt_enc_input1(v, p.inScale[stem * p.coeff_stem + c0 + c], p.inShift[stem * p.coeff_stem + c0 + c], actp);
             pin[i] = ok ? v : 0.0f;
         }
 #pragma unroll
@@ -357,21 +376,14 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
         }
     }
 
-    // epilogue: lane holds pixel l31 of each sub-tile and 16 output channels per accumulator.
-    // Per-channel constants are fetched once, unconditionally (clamped index), so the loads pipeline.
+    // epilogue: lane holds pixel l31 of each sub-tile and 16 output channels per accumulator; conv + bias is stored once
     const float* bias = p.bias + stem * p.coeff_stem;
-    const float* scale = p.bnScale ? p.bnScale + stem * p.coeff_stem : bias;
-    const float* shift = p.bnShift ? p.bnShift + stem * p.coeff_stem : bias;
-    const bool hasBn = p.bnScale != nullptr;
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        float bi[16], sc[16], sf[16];
+        float bi[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1);
-            bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
-        }
+        for (int r = 0; r < 16; ++r) bi[r] = bias[min(m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1)];
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int s = wn * NR + nr;
@@ -382,11 +394,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma(const SrtConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pix_ok && m < p.Cout) {
-                    const float v = acc[mr][nr][r] + bi[r];
-                    p.outRaw[obase + (size_t)m * ohw] = v;
-                    if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], actp);
-                }
+                if (pix_ok && m < p.Cout) p.outRaw[obase + (size_t)m * ohw] = acc[mr][nr][r] + bi[r];
             }
         }
     }

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     constexpr int WROWS = KC * 25, WSLAB = (WROWS * BM + 255) / 256 * 256;
 
     __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
-    __shared__ float s_epi[3 * BM];                     // bias / BN scale / BN shift of this workgroup's BM rows (see the epilogue)
+    __shared__ float s_epi[BM];                         // bias of this workgroup's BM rows (see the epilogue)
+    __shared__ float s_ibn[2 * SRT_ENC_MAX_CIN];        // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
 
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // offset and the validity of each of this thread's NLD float4 elements are computed ONCE: the per-chunk staging is
     // then a load, a select and two LDS stores per element (ablation: the index math was most of the 12 % this stage cost).
     ptrdiff_t goff[NLD];
-    int loff[NLD];
+    int loff[NLD], cix[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + i * 256, ec = min(e, NF4 - 1);
@@ -138,8 +139,15 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         const bool ok = e < NF4 && tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
         goff[i] = ok ? (ptrdiff_t)il * (ptrdiff_t)p.srcA_tile + (ptrdiff_t)c * (ptrdiff_t)hw + (ptrdiff_t)gy * p.W + gx : -1;
         loff[i] = e < NF4 ? c * CHS + il * INS + r * ROWS + 2 * j : -1;
+        cix[i] = c;
     }
     const float* srcBase = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;       // encoder layers read one source (CA == Cin)
+    // The source of layers 2..6 is the previous layer's RAW output (= the skip tensor, stored once): its batch-norm and
+    // activation (spleeter.c:188) are applied here, between the landed global load and the LDS store, with the reference's
+    // operation order, so the staged value is bit-identical to the `act` copy the producer used to write beside `raw`.
+    // Padding stays exactly zero (the select comes after the transform).  The constants are chunk-uniform per staged
+    // element (its channel is fixed, only the chunk base moves) and sit in LDS.
+    const bool xform = !STEMSTACK && p.inScale != nullptr;
     float4 pin[NLD];
     auto load_patch = [&](int c0) {
         const float* base = srcBase + (size_t)c0 * hw;
@@ -149,13 +157,15 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             pin[i] = goff[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_patch = [&]() {
+    auto store_patch = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (loff[i] >= 0) {
+                float4 v = pin[i];
+                if (xform) v = srt_enc_input4(v, s_ibn[c0 + cix[i]], s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]], goff[i] >= 0, actp);
                 float* d = s_in + loff[i];
-                *reinterpret_cast<float2*>(d) = make_float2(pin[i].x, pin[i].z);            // even columns -> plane 0
-                *reinterpret_cast<float2*>(d + PWH) = make_float2(pin[i].y, pin[i].w);      // odd columns  -> plane 1
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.z);            // even columns -> plane 0
+                *reinterpret_cast<float2*>(d + PWH) = make_float2(v.y, v.w);      // odd columns  -> plane 1
             }
         }
     };
@@ -181,21 +191,24 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // Epilogue constants go through LDS BEFORE the K loop.  Loaded from global memory at the start of the epilogue they put a
     // counted s_waitcnt vmcnt(n) in front of every output element, and since stores count in vmcnt too each of those waits also
     // drained the stores issued so far: the epilogue ran at one store round trip per element (0.36 ms of down2's 1.08 ms).
-    const bool hasBn = p.bnScale != nullptr;
     const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
     if (tid < BM) {
         const int m = min(m0 + tid, mlimit - 1);
         const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
-        const size_t ci = st * p.coeff_stem + co;
-        s_epi[tid] = p.bias[ci];
-        s_epi[BM + tid] = hasBn ? p.bnScale[ci] : 0.0f;
-        s_epi[2 * BM + tid] = hasBn ? p.bnShift[ci] : 0.0f;
+        s_epi[tid] = p.bias[st * p.coeff_stem + co];
+    }
+    if (xform) {
+        for (int c = tid; c < p.Cin; c += 256) {
+            s_ibn[c] = p.inScale[stem * p.coeff_stem + c];
+            s_ibn[SRT_ENC_MAX_CIN + c] = p.inShift[stem * p.coeff_stem + c];
+        }
+        __syncthreads();
     }
     const int nchunks = p.Cin / KC;
     srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
     load_patch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        if ((ABL != 1 && ABL != 4) || ch == 0) store_patch();
+        if ((ABL != 1 && ABL != 4) || ch == 0) store_patch(ch * KC);
         __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
         const float* sw = s_w + (ch & 1) * WSLAB;
         if (ch + 1 < nchunks && ABL != 1) {       // issued up front; spreading the pieces between the MFMAs measured no gain
@@ -224,27 +237,20 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     }
 
     if (ABL == 7) return;                                  // ablation: no epilogue
+    // epilogue: conv + bias, stored ONCE (the skip tensor is also the next layer's input; see store_patch)
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        float bi[16], sc[16], sf[16];
+        float bi[16];
         size_t ob[16];
-        unsigned elu[16];                      // stem-stacked rows: the activation kind follows the row's stem
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int m = min(m0 + row, mlimit - 1);
             const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
             bi[r] = s_epi[row];
-            sc[r] = s_epi[BM + row];
-            sf[r] = s_epi[2 * BM + row];
             ob[r] = st * p.out_stem + (size_t)co * ohw;
-            if (STEMSTACK) elu[r] = (p.elu_mask >> st) & 1u;
         }
-        // stem-stacked rows (down1, Cout == 16): registers 0..7 are one stem's channels and 8..15 the next stem's, so the
-        // activation parameters are two launch-uniform triples, not something to re-derive for each of the 64 outputs
-        const SrtAct apg[2] = { srt_act_params(STEMSTACK && elu[0] ? SRT_ACT_ELU : p.act, p.variant),
-                                srt_act_params(STEMSTACK && elu[8] ? SRT_ACT_ELU : p.act, p.variant) };
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int s = wn * NR + nr;
@@ -252,31 +258,10 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
             const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
             const size_t pbase = (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
-            if (STEMSTACK) {
-                // a 16-row group is one stem: it is valid or not as a whole, so the 64 outputs of a thread sit behind 8 branches
-                if (pix_ok) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        if (m0 + (wm * MR + mr) * 32 + 16 * g < mlimit) {
-#pragma unroll
-                            for (int r = 8 * g; r < 8 * g + 8; ++r) {
-                                const float v = acc[mr][nr][r] + bi[r];
-                                p.outRaw[ob[r] + pbase] = v;
-                                if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], apg[g]);
-                            }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (pix_ok && m < mlimit) {
-                        const float v = acc[mr][nr][r] + bi[r];
-                        p.outRaw[ob[r] + pbase] = v;
-                        if (hasBn) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc[r], sf[r], actp);
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pix_ok && m < mlimit) p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
             }
         }
     }

@@ -231,9 +231,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
     constexpr int WSLAB = 25 * 512;
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
-    // bias / BN scale / BN shift of the 32 rows, staged before the K loop (see srt_enc_mfma2) - unless the tile already fills the LDS
-    constexpr bool EPI_LDS = sizeof(_Float16) * (NSPLIT * 2 * PLANE + 2 * WSLAB) + 96 * sizeof(float) <= 160 * 1024;
-    __shared__ float s_epi[EPI_LDS ? 96 : 1];
+    __shared__ float s_epi[32];                             // bias of the 32 rows, staged before the K loop (see srt_enc_mfma2)
+    __shared__ float s_ibn[2 * SRT_ENC_MAX_CIN];            // BN scale | shift of the input channels (applied while staging)
+    static_assert(sizeof(_Float16) * (NSPLIT * 2 * PLANE + 2 * WSLAB) + (32 + 2 * SRT_ENC_MAX_CIN) * sizeof(float) <= 160 * 1024, "LDS");
     _Float16* s_in = s_mem;
     _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
 
@@ -265,17 +265,24 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
             }
         }
     };
-    auto store_patch = [&]() {
+    // the source of down2..down6 is the previous layer's conv + bias: its BN + activation is applied here, in fp32, before the
+    // fp16 rounding (see srt_enc_mfma2); padding stays exactly zero
+    const bool xform = p.inScale != nullptr;
+    auto store_patch = [&](int cg) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * 256;
             if (e < NIT) {
                 const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
+                const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
+                const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
                 _Float16* d = s_in + gg * PLANE + ((il * PH + r) * ROWS + 2 * j) * 8;   // plane 0 halves 2j,2j+1; plane 1 at +PWH
                 h8 hi[4], lo[4];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float x[4] = { pin[i][q].x, pin[i][q].y, pin[i][q].z, pin[i][q].w };
+                    float4 pv = pin[i][q];
+                    if (xform) { const int c = cg * 16 + gg * 8 + q; pv = srt_enc_input4(pv, s_ibn[c], s_ibn[SRT_ENC_MAX_CIN + c], ok, actp); }
+                    const float x[4] = { pv.x, pv.y, pv.z, pv.w };
 #pragma unroll
                     for (int px = 0; px < 4; ++px) {
                         _Float16 a, b;
@@ -308,16 +315,19 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     }
     const int aoff = (g * BM + l31) * 8;
 
-    const bool hasBn = p.bnScale != nullptr;
-    if (EPI_LDS && tid < 32) {
-        const size_t ci = stem * p.coeff_stem + min(m0 + tid, p.Cout - 1);
-        s_epi[tid] = p.bias[ci]; s_epi[32 + tid] = hasBn ? p.bnScale[ci] : 0.0f; s_epi[64 + tid] = hasBn ? p.bnShift[ci] : 0.0f;
+    if (tid < 32) s_epi[tid] = p.bias[stem * p.coeff_stem + min(m0 + tid, p.Cout - 1)];
+    if (xform) {
+        for (int c = tid; c < p.Cin; c += 256) {
+            s_ibn[c] = p.inScale[stem * p.coeff_stem + c];
+            s_ibn[SRT_ENC_MAX_CIN + c] = p.inShift[stem * p.coeff_stem + c];
+        }
+        __syncthreads();
     }
     const int nchunks = p.Cin / 16;
     srt_dma_slab16(wp, p.CP, s_w, wave, lane);
     load_patch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_patch();
+        store_patch(ch);
         __syncthreads();
         const _Float16* sw = s_w + (ch & 1) * WSLAB;
         if (ch + 1 < nchunks) {
@@ -343,16 +353,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     }
 
     const size_t ohw = (size_t)Ho * Wo;
-    float bi[16], sc[16], sf[16];
+    float bi[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-        if (EPI_LDS) { bi[r] = s_epi[row]; sc[r] = s_epi[32 + row]; sf[r] = s_epi[64 + row]; }
-        else {
-            const size_t ci = stem * p.coeff_stem + min(m0 + row, p.Cout - 1);
-            bi[r] = p.bias[ci]; sc[r] = hasBn ? p.bnScale[ci] : 0.0f; sf[r] = hasBn ? p.bnShift[ci] : 0.0f;
-        }
-    }
+    for (int r = 0; r < 16; ++r) bi[r] = s_epi[(r & 3) + 8 * (r >> 2) + 4 * g];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int s = wave * NR + nr;
@@ -363,11 +366,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (pix_ok && m < p.Cout) {
-                const float v = acc[nr][r] + bi[r];
-                p.outRaw[obase + (size_t)m * ohw] = v;
-                if (hasBn) p.outAct[obase + (size_t)m * ohw] = srt_enc_epilogue(v, sc[r], sf[r], actp);
-            }
+            if (pix_ok && m < p.Cout) p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];      // conv + bias, stored once
         }
     }
 }
@@ -410,8 +409,7 @@ int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
         if (v == 1) return launch_enc16<32, 1, 8, 1>(p, s);                  // one 8x32 instance
         return launch_enc16<32, 1, 4, 1>(p, s);
     }
-    if (v == 1) return launch_enc16<16, 1, 2, 4>(p, s);                      // 4 instances of 4x16
-    return launch_enc16<16, 1, 2, 2>(p, s);                                  // 2 instances of 4x16
+    return launch_enc16<16, 1, 2, 2>(p, s);                                  // 2 instances of 4x16 (4 instances of the split form do not fit the LDS beside the input-BN table)
 }
 int srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s)
 {

@@ -13,9 +13,21 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <vector>
 
-#define HIPDIE(x, where) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "libspleeterrt_amd: %s: %s\n", where, hipGetErrorString(_e)); abort(); } } while (0)
+// Failure policy (this is the host's real-time audio thread, VST/Source/PluginProcessor.cpp:178-179): never abort(), never a
+// CPU path.  The first failure is reported once (stderr + srtLastError()), the instance is marked failed and from then on it
+// emits SILENCE with the reference's exact sample accounting, without touching the device again.
+static bool stream_fail(const char* where, const char* why)
+{
+    char buf[400];
+    snprintf(buf, sizeof buf, "%s: %s", where, why ? why : srtLastError());
+    srt_set_error(-2, "%s", buf);
+    fprintf(stderr, "libspleeterrt_amd: %s (no CPU fallback exists; the stream is muted)\n", buf);
+    return false;
+}
+#define HIPTRY(x, where) do { hipError_t _e = (x); if (_e != hipSuccess) { s->failed = true; stream_fail(where, hipGetErrorString(_e)); goto failed; } } while (0)
 
 namespace {
 struct Stream {
@@ -23,14 +35,14 @@ struct Stream {
     hipStream_t hop, nn;
     hipEvent_t evMag, evNN;
     int F, T, cursor, ptr;
-    bool nnRunning;
+    bool nnRunning, failed;
     float* d_ring; float2* d_spec; float* d_mag; float* d_tmp; float* d_masks; float* d_overlap; float* d_out;
     float *d_awin, *d_swin; float2* d_tw;
     size_t hw;
     // host state, mirrors Spleeter4Stems.h:35-47
     float ring[2][FFTSIZE];
     unsigned inPos, needed;
-    float* outq[2]; float* pinned;            // two queued segments of OUTPUTSEG*8 floats (pinned for the D2H copy)
+    float* outq[2]; float* pinned; float* hostq; // two queued segments of OUTPUTSEG*8 floats (pinned for the D2H copy; plain host memory on a failed instance)
     int outCount, outReadOff;
 };
 
@@ -52,99 +64,126 @@ void asymmetric_window(std::vector<float>& an, std::vector<float>& sy)      // S
 void process_hop(Stream* s)                                                  // LLPAMSProcessNPR, Spleeter4Stems.c:257-381
 {
     const size_t rowF2 = SRT_SPEC_LD, bufF2 = 2 * (size_t)s->T * rowF2;
-    HIPDIE(hipMemcpyAsync(s->d_ring, s->ring, sizeof s->ring, hipMemcpyHostToDevice, s->hop), "stream hop");
-    SrtStreamHop p; memset(&p, 0, sizeof p);
-    p.ring = s->d_ring; p.inPos = (int)s->inPos;
-    p.specRow = s->d_spec + s->ptr * bufF2 + (size_t)s->cursor * rowF2; p.specChStride = (size_t)s->T * rowF2;
-    p.magRow = s->d_mag + (size_t)s->cursor * s->F; p.magChStride = s->hw;
-    p.maskRow = s->d_masks + (size_t)s->ptr * 4 * 2 * s->hw + (size_t)s->cursor * s->F; p.maskStemStride = 2 * s->hw; p.maskChStride = s->hw;
-    p.F = s->F; p.overlap = s->d_overlap; p.out = s->d_out;
-    p.analysisWnd = s->d_awin; p.synthesisWnd = s->d_swin; p.twiddle = s->d_tw;
-    if (srt_launch_stream_hop(p, s->hop)) { fprintf(stderr, "libspleeterrt_amd: stream hop launch failed\n"); abort(); }
     if (s->outCount >= 2) { float* t = s->outq[0]; s->outq[0] = s->outq[1]; s->outq[1] = t; s->outCount = 1; s->outReadOff = 0; }   // the reference overruns its 2-slot queue here (caller passed > 1024 samples without draining); drop the oldest segment instead
     float* dst = s->outq[s->outCount];
-    HIPDIE(hipMemcpyAsync(dst, s->d_out, OUTPUTSEG * 8 * sizeof(float), hipMemcpyDeviceToHost, s->hop), "stream hop");
     s->outCount++;
-    s->cursor++;
-    if (s->cursor >= s->T) {
-        // join the networks started one batch ago (their masks land in buffer !ptr), flip, start on this batch's magnitudes
-        if (s->nnRunning) HIPDIE(hipStreamWaitEvent(s->hop, s->evNN, 0), "stream join");
-        s->ptr = !s->ptr;
-        HIPDIE(hipMemcpyAsync(s->d_tmp, s->d_mag, 2 * s->hw * sizeof(float), hipMemcpyDeviceToDevice, s->hop), "stream flip");   // "Prevent race condition" copy (:364-365)
-        HIPDIE(hipEventRecord(s->evMag, s->hop), "stream flip");
-        HIPDIE(hipStreamWaitEvent(s->nn, s->evMag, 0), "stream flip");
-        if (srtForward(s->eng, s->d_tmp, 1, s->d_masks + (size_t)(!s->ptr) * 4 * 2 * s->hw)) { fprintf(stderr, "libspleeterrt_amd: %s\n", srtLastError()); abort(); }
-        HIPDIE(hipEventRecord(s->evNN, s->nn), "stream flip");
-        s->nnRunning = true;
-        s->cursor = 0;
-    }
-    HIPDIE(hipStreamSynchronize(s->hop), "stream hop");                      // the segment must be in host memory before the callback returns
     s->needed = OUTPUTSEG;
+    if (s->failed) goto failed;
+    {
+        HIPTRY(hipMemcpyAsync(s->d_ring, s->ring, sizeof s->ring, hipMemcpyHostToDevice, s->hop), "stream hop");
+        SrtStreamHop p; memset(&p, 0, sizeof p);
+        p.ring = s->d_ring; p.inPos = (int)s->inPos;
+        p.specRow = s->d_spec + s->ptr * bufF2 + (size_t)s->cursor * rowF2; p.specChStride = (size_t)s->T * rowF2;
+        p.magRow = s->d_mag + (size_t)s->cursor * s->F; p.magChStride = s->hw;
+        p.maskRow = s->d_masks + (size_t)s->ptr * 4 * 2 * s->hw + (size_t)s->cursor * s->F; p.maskStemStride = 2 * s->hw; p.maskChStride = s->hw;
+        p.F = s->F; p.overlap = s->d_overlap; p.out = s->d_out;
+        p.analysisWnd = s->d_awin; p.synthesisWnd = s->d_swin; p.twiddle = s->d_tw;
+        if (srt_launch_stream_hop(p, s->hop)) { s->failed = true; stream_fail("stream hop", "kernel launch failed"); goto failed; }
+        HIPTRY(hipMemcpyAsync(dst, s->d_out, OUTPUTSEG * 8 * sizeof(float), hipMemcpyDeviceToHost, s->hop), "stream hop");
+        s->cursor++;
+        if (s->cursor >= s->T) {
+            // join the networks started one batch ago (their masks land in buffer !ptr), flip, start on this batch's magnitudes
+            if (s->nnRunning) HIPTRY(hipStreamWaitEvent(s->hop, s->evNN, 0), "stream join");
+            s->ptr = !s->ptr;
+            HIPTRY(hipMemcpyAsync(s->d_tmp, s->d_mag, 2 * s->hw * sizeof(float), hipMemcpyDeviceToDevice, s->hop), "stream flip");   // "Prevent race condition" copy (:364-365)
+            HIPTRY(hipEventRecord(s->evMag, s->hop), "stream flip");
+            HIPTRY(hipStreamWaitEvent(s->nn, s->evMag, 0), "stream flip");
+            if (srtForward(s->eng, s->d_tmp, 1, s->d_masks + (size_t)(!s->ptr) * 4 * 2 * s->hw)) { s->failed = true; stream_fail("stream networks", nullptr); goto failed; }
+            HIPTRY(hipEventRecord(s->evNN, s->nn), "stream flip");
+            s->nnRunning = true;
+            s->cursor = 0;
+        }
+        HIPTRY(hipStreamSynchronize(s->hop), "stream hop");                  // the segment must be in host memory before the callback returns
+        return;
+    }
+failed:
+    memset(dst, 0, OUTPUTSEG * 8 * sizeof(float));                           // silence for this hop, same sample accounting
 }
 }  // namespace
 
 void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4])
 {
-    Stream* s = new Stream();
-    memset(s, 0, sizeof *s);
-    s->F = F; s->T = T; s->hw = (size_t)F * T;
-    HIPDIE(hipStreamCreate(&s->hop), "Spleeter4StemsInit");
-    HIPDIE(hipStreamCreate(&s->nn), "Spleeter4StemsInit");
-    HIPDIE(hipEventCreateWithFlags(&s->evMag, hipEventDisableTiming), "Spleeter4StemsInit");
-    HIPDIE(hipEventCreateWithFlags(&s->evNN, hipEventDisableTiming), "Spleeter4StemsInit");
-    srt_config cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.F = F; cfg.T = T; cfg.n_stems = 4; cfg.variant = SRT_VARIANT_VST; cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA;
-    for (int k = 0; k < 4; ++k) { cfg.stem_mode[k] = 1; cfg.oob_weight[k] = k == 1 ? 0.0f : 0.25f; }      // Spleeter4Stems.c:444-447
-    if (srtCreate(&cfg, s->nn, &s->eng)) { fprintf(stderr, "libspleeterrt_amd: Spleeter4StemsInit: %s\n", srtLastError()); abort(); }
-    for (int k = 0; k < 4; ++k)
-        if (srtSetCoeffHost(s->eng, k, coeffProvider[k])) { fprintf(stderr, "libspleeterrt_amd: Spleeter4StemsInit: %s\n", srtLastError()); abort(); }
-    const size_t specF = 2 * 2 * (size_t)T * SRT_SPEC_LD * 2;
-    HIPDIE(hipMalloc((void**)&s->d_ring, sizeof s->ring), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_spec, specF * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_mag, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_tmp, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_masks, 2 * 4 * 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_overlap, 8 * 1024 * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_out, OUTPUTSEG * 8 * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_awin, FFTSIZE * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_swin, FFTSIZE * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMalloc((void**)&s->d_tw, FFTSIZE * sizeof(float2)), "Spleeter4StemsInit");
-    HIPDIE(hipMemset(s->d_spec, 0, specF * sizeof(float)), "Spleeter4StemsInit");              // zero spectrum for the first 2T hops (:423-438)
-    HIPDIE(hipMemset(s->d_mag, 0, 2 * s->hw * sizeof(float)), "Spleeter4StemsInit");
-    HIPDIE(hipMemset(s->d_overlap, 0, 8 * 1024 * sizeof(float)), "Spleeter4StemsInit");
-    std::vector<float> ones(2 * 4 * 2 * s->hw, 1.0f), an, sy, tw(2 * FFTSIZE);                 // masks start at 1.0 (:456-467)
-    HIPDIE(hipMemcpy(s->d_masks, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice), "Spleeter4StemsInit");
-    asymmetric_window(an, sy);
-    const double w0 = 6.283185307179586476925286766559 / FFTSIZE;
-    for (int i = 0; i < FFTSIZE; ++i) { tw[2 * i] = (float)cos(w0 * i); tw[2 * i + 1] = (float)(-sin(w0 * i)); }
-    HIPDIE(hipMemcpy(s->d_awin, an.data(), FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
-    HIPDIE(hipMemcpy(s->d_swin, sy.data(), FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
-    HIPDIE(hipMemcpy(s->d_tw, tw.data(), 2 * FFTSIZE * 4, hipMemcpyHostToDevice), "Spleeter4StemsInit");
-    HIPDIE(hipHostMalloc((void**)&s->pinned, 2 * OUTPUTSEG * 8 * sizeof(float), hipHostMallocDefault), "Spleeter4StemsInit");
-    s->outq[0] = s->pinned; s->outq[1] = s->pinned + OUTPUTSEG * 8;
-    s->needed = OUTPUTSEG; s->inPos = 0; s->outCount = 0; s->outReadOff = 0; s->cursor = 0; s->ptr = 0; s->nnRunning = false;
+    if (!msr) return;
     memset(msr, 0, sizeof *msr);
+    Stream* s = new (std::nothrow) Stream();
+    if (!s) { stream_fail("Spleeter4StemsInit", "out of host memory"); return; }
+    memset(s, 0, sizeof *s);
     msr->impl = s;
+    s->F = F; s->T = T; s->hw = (size_t)F * T;
+    s->needed = OUTPUTSEG;
+    // host-side queue first: a failed instance still accounts for samples (and emits silence) through it
+    s->pinned = nullptr;
+    s->hostq = (float*)calloc(2 * OUTPUTSEG * 8, sizeof(float));
+    s->outq[0] = s->hostq; s->outq[1] = s->hostq ? s->hostq + OUTPUTSEG * 8 : nullptr;
+    s->failed = true;                                    // until everything below has succeeded
+    if (!s->hostq) { stream_fail("Spleeter4StemsInit", "out of host memory"); return; }
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { stream_fail("Spleeter4StemsInit", "no HIP device (this library has no CPU path)"); return; }
+        for (int k = 0; k < 4; ++k) if (!coeffProvider || !coeffProvider[k]) { stream_fail("Spleeter4StemsInit", "null coefficient pointer"); return; }
+#define INITTRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { stream_fail("Spleeter4StemsInit", hipGetErrorString(_e)); return; } } while (0)
+        INITTRY(hipStreamCreate(&s->hop));
+        INITTRY(hipStreamCreate(&s->nn));
+        INITTRY(hipEventCreateWithFlags(&s->evMag, hipEventDisableTiming));
+        INITTRY(hipEventCreateWithFlags(&s->evNN, hipEventDisableTiming));
+        srt_config cfg; memset(&cfg, 0, sizeof cfg);
+        cfg.F = F; cfg.T = T; cfg.n_stems = 4; cfg.variant = SRT_VARIANT_VST; cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA;
+        for (int k = 0; k < 4; ++k) { cfg.stem_mode[k] = 1; cfg.oob_weight[k] = k == 1 ? 0.0f : 0.25f; }      // Spleeter4Stems.c:444-447
+        if (srtCreate(&cfg, s->nn, &s->eng)) { s->eng = nullptr; stream_fail("Spleeter4StemsInit", nullptr); return; }
+        for (int k = 0; k < 4; ++k)
+            if (srtSetCoeffHost(s->eng, k, coeffProvider[k])) { stream_fail("Spleeter4StemsInit(weights)", nullptr); return; }
+        const size_t specF = 2 * 2 * (size_t)T * SRT_SPEC_LD * 2;
+        INITTRY(hipMalloc((void**)&s->d_ring, sizeof s->ring));
+        INITTRY(hipMalloc((void**)&s->d_spec, specF * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_mag, 2 * s->hw * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_tmp, 2 * s->hw * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_masks, 2 * 4 * 2 * s->hw * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_overlap, 8 * 1024 * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_out, OUTPUTSEG * 8 * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_awin, FFTSIZE * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_swin, FFTSIZE * sizeof(float)));
+        INITTRY(hipMalloc((void**)&s->d_tw, FFTSIZE * sizeof(float2)));
+        INITTRY(hipMemset(s->d_spec, 0, specF * sizeof(float)));              // zero spectrum for the first 2T hops (:423-438)
+        INITTRY(hipMemset(s->d_mag, 0, 2 * s->hw * sizeof(float)));
+        INITTRY(hipMemset(s->d_overlap, 0, 8 * 1024 * sizeof(float)));
+        std::vector<float> ones(2 * 4 * 2 * s->hw, 1.0f), an, sy, tw(2 * FFTSIZE);                 // masks start at 1.0 (:456-467)
+        INITTRY(hipMemcpy(s->d_masks, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+        asymmetric_window(an, sy);
+        const double w0 = 6.283185307179586476925286766559 / FFTSIZE;
+        for (int i = 0; i < FFTSIZE; ++i) { tw[2 * i] = (float)cos(w0 * i); tw[2 * i + 1] = (float)(-sin(w0 * i)); }
+        INITTRY(hipMemcpy(s->d_awin, an.data(), FFTSIZE * 4, hipMemcpyHostToDevice));
+        INITTRY(hipMemcpy(s->d_swin, sy.data(), FFTSIZE * 4, hipMemcpyHostToDevice));
+        INITTRY(hipMemcpy(s->d_tw, tw.data(), 2 * FFTSIZE * 4, hipMemcpyHostToDevice));
+        INITTRY(hipHostMalloc((void**)&s->pinned, 2 * OUTPUTSEG * 8 * sizeof(float), hipHostMallocDefault));   // pinned queue for the per-hop D2H copy
+#undef INITTRY
+        s->outq[0] = s->pinned; s->outq[1] = s->pinned + OUTPUTSEG * 8;
+    }
+    s->failed = false;
 }
 
 void Spleeter4StemsFree(Spleeter4Stems* msr)
 {
     if (!msr || !msr->impl) return;
     Stream* s = (Stream*)msr->impl;
-    hipStreamSynchronize(s->hop); hipStreamSynchronize(s->nn);
-    srtDestroy(s->eng);
+    if (s->hop) hipStreamSynchronize(s->hop);
+    if (s->nn) hipStreamSynchronize(s->nn);
+    if (s->eng) srtDestroy(s->eng);
     void* d[] = { s->d_ring, s->d_spec, s->d_mag, s->d_tmp, s->d_masks, s->d_overlap, s->d_out, s->d_awin, s->d_swin, s->d_tw };
-    for (void* q : d) hipFree(q);
-    hipHostFree(s->pinned);
-    hipEventDestroy(s->evMag); hipEventDestroy(s->evNN);
-    hipStreamDestroy(s->hop); hipStreamDestroy(s->nn);
+    for (void* q : d) if (q) hipFree(q);
+    if (s->pinned) hipHostFree(s->pinned);
+    free(s->hostq);
+    if (s->evMag) hipEventDestroy(s->evMag);
+    if (s->evNN) hipEventDestroy(s->evNN);
+    if (s->hop) hipStreamDestroy(s->hop);
+    if (s->nn) hipStreamDestroy(s->nn);
     delete s;
     msr->impl = nullptr;
 }
 
 void Spleeter4StemsProcessSamples(Spleeter4Stems* msr, const float* inLeft, const float* inRight, int inSampleCount, float** components)
 {
-    Stream* s = (Stream*)msr->impl;
+    Stream* s = msr ? (Stream*)msr->impl : nullptr;
+    if (!s || !s->outq[0]) return;                                          // Init could not even allocate its host state: nothing is written
     int outSampleCount = 0;
     const int maxOut = inSampleCount;
     while (inSampleCount > 0) {                                             // Spleeter4Stems.c:518-537

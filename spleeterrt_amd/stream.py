@@ -45,6 +45,36 @@ def plan(n, T, max_tiles, rank=0, world=1):
     return out
 
 
+Span = namedtuple("Span", "tile0 tile1 sample0 nsamples frames rows out_offset")
+
+
+def rank_span(n, T, rank=0, world=1):
+    """The contiguous tile range of one rank as ONE span (what srtSeparateHostStream chunks natively): tiles
+    [tile0, tile1), PCM samples [sample0, sample0 + nsamples) (3072-sample halo included), `frames` transformed
+    frames, `rows` rows, and the offset of its overlap-add contribution in the full output."""
+    rows, frames = stft_rows(n), stft_frames(n)
+    ntiles = (rows + T - 1) // T
+    t0, t1 = rank_tiles(ntiles, rank, world)
+    row0, row1 = t0 * T, min(t1 * T, rows)
+    s0 = row0 * HOP
+    ns = max(0, min(n, row1 * HOP + (FFT - HOP)) - s0)
+    return Span(t0, t1, s0, ns, max(0, min(frames - row0, row1 - row0)), max(0, row1 - row0), s0)
+
+
+def separate_host_range(engine, L, R, rank=0, world=1, out=None, pinned=False):
+    """This rank's share of a HOST-resident stream (numpy / pinned arrays of the whole stream, or anything sliceable):
+    one srtSeparateHostStream call over its tile range — chunks of engine.max_tiles tiles, H2D / compute / D2H overlapped
+    on three HIP streams, chunk overlaps carried on the device.  Returns (span, stems [S,2,rows*1024+3072]) or
+    (span, None) when the rank has no tiles.  The reference's counterpart is one tile-range worker of processMT
+    (Executable/main.c:544-673); there is no exchange with other ranks."""
+    sp = rank_span(len(L), engine.T, rank, world)
+    if sp.rows == 0:
+        return sp, None
+    o = engine.separate_host_stream(L[sp.sample0:sp.sample0 + sp.nsamples], R[sp.sample0:sp.sample0 + sp.nsamples],
+                                    frames=sp.frames, rows=sp.rows, out=out, pinned=pinned)
+    return sp, o
+
+
 def total_output_length(n):
     return stft_rows(n) * HOP + (FFT - HOP)                       # stftFix.c:500
 

@@ -317,6 +317,42 @@ def test_fp16_mfma_variants(oracle, coeffs, prec, mask_tol, T, F):
     eng.close()
 
 
+@pytest.mark.parametrize("prec,mask_tol,stem_tol", [("f16", 2e-2, 1e-2), ("f16x2", MASK_TOL_EXACT, 1e-4)])
+def test_config4_five_stems_fp16_end_to_end(oracle, coeffs, prec, mask_tol, stem_tol):
+    """BASELINE configs[4] as named: 5 stems (the fifth = one more spleeterCoeff blob), T=256, F=1024, fp16-MFMA conv
+    with fp32 STFT / iSTFT, PCM -> stems, tolerance-checked against the CPU fp32 oracle: mask max-abs <= 2e-2 and stems rel-RMS <= 1e-2
+    (BASELINE.md §4).  The split form (f16x2, exact products for fp16-representable weights) is held to the fp32 tolerances."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S = 256, 1024, 5
+    n = T * 1024                                              # one tile: 256 rows, 253 transformed frames
+    L, R = oracle.synth_audio(n, 2025, True)
+    oob = (0.25, 0.0, 0.25, 0.25, 0.1)
+    eng = _engine(F=F, T=T, stem_modes=(1,) * S, oob_weights=oob, variant=srt.VARIANT_VST, max_tiles=1,
+                  precision=srt.PREC_F16 if prec == "f16" else srt.PREC_F16X2)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = eng.separate(Ld, Rd).cpu().numpy()
+    spec, mag = eng.stft(Ld, Rd)
+    masks = eng.forward(mag).cpu().numpy()
+    re, im = oracle.stft(L, R)
+    assert re.shape[1] == T
+    x = oracle.magnitude_tile(re, im, 0, T, F)
+    worst_m = worst_s = 0.0
+    for s in range(S):
+        y = oracle.forward(coeffs(s), x, 1, oracle.VARIANT_VST)
+        worst_m = max(worst_m, float(np.abs(masks[s, 0] - y).max()))
+        r, i = re.copy(), im.copy()
+        r[:, :, :F] *= y; i[:, :, :F] *= y                    # main.c:473-485 (one full tile: no tail rows)
+        r[:, :, F:2049] *= np.float32(oob[s]); i[:, :, F:2049] *= np.float32(oob[s])    # main.c:486-493
+        ref = oracle.istft(r, i)
+        worst_s = max(worst_s, _rel_rms(out[s], ref))
+    print("configs[4] %s: worst mask err %.3g, worst stem rel rms %.3g" % (prec, worst_m, worst_s))
+    assert worst_m <= mask_tol and worst_s <= stem_tol
+    eng.close()
+
+
 @pytest.mark.parametrize("stems", [2, 3])
 def test_cli_flow_device_resident(oracle, coeffs, stems):
     """srtSeparateCli == the offline CLI's flow restated over the oracle (main.c:776-798 two outputs with the time-domain

@@ -29,13 +29,13 @@ def _run(lib, struct_bytes, coeffs, F, T, L, R, chunks):
     return out
 
 
-@pytest.mark.parametrize("chunks", [(1024,), (300, 724, 1024, 512, 17)])
-def test_streaming_matches_reference(oracle, coeffs, chunks):
+@pytest.mark.parametrize("T,F,chunks", [(64, 512, (1024,)), (64, 512, (300, 724, 1024, 512, 17)),
+                                        (256, 1536, (480, 1024, 544))])   # last: the geometry the plugin ships (PluginProcessor.cpp:124)
+def test_streaming_matches_reference(oracle, coeffs, T, F, chunks):
     if oracle.ref_path("stream") is None:
         pytest.skip("oracle/_ref/libspleeter_ref_stream.so not built")
     import spleeterrt_amd
-    T, F = 64, 512
-    hops = 3 * T + 9                                            # masks of batch 0 become audible after 2T hops
+    hops = 3 * T + 9 if T == 64 else 2 * T + T // 2             # masks of batch 0 become audible after 2T hops
     n = hops * 1024
     L, R = oracle.synth_audio(n, 4711, True)
     cs = [np.ascontiguousarray(coeffs(k)) for k in range(4)]
