@@ -30,10 +30,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO):
-        raise EngineError("%s not built: run `python -m spleeterrt_amd.build` (needs hipcc); no CPU fallback exists" % SO)
+    so = os.environ.get("SPLEETERRT_LIB") or SO           # SPLEETERRT_LIB: the -DSRT_TUNING measurement build (scripts/tune.sh)
+    if not os.path.exists(so):
+        raise EngineError("%s not built: run `python -m spleeterrt_amd.build` (needs hipcc); no CPU fallback exists" % so)
     import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
-    L = C.CDLL(SO)
+    L = C.CDLL(so)
     vp, f32p = C.c_void_p, C.c_void_p
     L.srtCreate.argtypes = [C.POINTER(_Config), vp, C.POINTER(vp)]
     L.srtDestroy.argtypes = [vp]

@@ -47,21 +47,29 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
 }
 // Consumer-side form of the encoder's batch-norm + activation (spleeter.c:188): the producing layer stores conv + bias once
 // (the skip tensor) and the next encoder layer applies act(scale * v + shift) to the four staged values of one channel.
-// `ok` false = padding, which must stay exactly zero.  The ELU / non-ELU choice is workgroup-uniform (a scalar branch), so
-// LeakyReLU stems do not pay for a v_exp_f32 per staged value.  Same operations, same order as srt_enc_epilogue.
+// Padding must stay exactly zero: the CALLER passes scale = shift = 0 for padded elements (their staged value is 0 or any finite
+// number), which gives act(0 * v + 0) = 0 for every activation kind without a per-element select - hipcc turns a select around
+// this much arithmetic into a divergent branch per element.  The ELU / non-ELU choice is workgroup-uniform (a scalar branch),
+// so LeakyReLU stems do not pay for a v_exp_f32 per staged value.  Same operations, same order as srt_enc_epilogue.
+__device__ __forceinline__ float srt_bn(float v, float scale, float shift) { return scale * v + shift; }      // contraction is off here
+__device__ __forceinline__ float srt_act_lin(float x, const SrtAct& a) { return x >= 0.0f ? x : a.lin * x; }   // LeakyReLU / ReLU stems
 __device__ __forceinline__ float srt_enc_input1(float v, float scale, float shift, const SrtAct& a)
 {
     const float x = scale * v + shift;
     if (a.ue != 0.0f) return srt_act_apply(x, a);
     return x >= 0.0f ? x : a.lin * x;
 }
-__device__ __forceinline__ float4 srt_enc_input4(float4 v, float scale, float shift, bool ok, const SrtAct& a)
+__device__ __forceinline__ float4 srt_enc_input4(float4 v, float scale, float shift, const SrtAct& a)
 {
     float4 o;
-    o.x = ok ? srt_enc_input1(v.x, scale, shift, a) : 0.0f;
-    o.y = ok ? srt_enc_input1(v.y, scale, shift, a) : 0.0f;
-    o.z = ok ? srt_enc_input1(v.z, scale, shift, a) : 0.0f;
-    o.w = ok ? srt_enc_input1(v.w, scale, shift, a) : 0.0f;
+    if (a.ue != 0.0f) {
+        o.x = srt_act_apply(scale * v.x + shift, a); o.y = srt_act_apply(scale * v.y + shift, a);
+        o.z = srt_act_apply(scale * v.z + shift, a); o.w = srt_act_apply(scale * v.w + shift, a);
+    } else {
+        const float x0 = scale * v.x + shift, x1 = scale * v.y + shift, x2 = scale * v.z + shift, x3 = scale * v.w + shift;
+        o.x = x0 >= 0.0f ? x0 : a.lin * x0; o.y = x1 >= 0.0f ? x1 : a.lin * x1;
+        o.z = x2 >= 0.0f ? x2 : a.lin * x2; o.w = x3 >= 0.0f ? x3 : a.lin * x3;
+    }
     return o;
 }
 // branchy forms (naive cross-check kernels)
@@ -98,12 +106,15 @@ __device__ __forceinline__ int srt_xcd_order(int total)
     const int q = total >> 3, r = total & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
-struct SrtBlockCoord { int sp, mblk, stem, grp; };
+struct SrtBlockCoord { int sp, mblk, stem, grp, ks; };
 // order: w = (stem, mblk) slowest, then instance group, then spatial tile (fastest: neighbours share halo rows)
-__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp)
+// ksplit > 1 (split-K launches): the K slice is the fastest index, so the workgroups that share one input patch are neighbours
+__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp, int ksplit = 1)
 {
-    const int pos = srt_xcd_order(nsp * nmb * nstem * ngrp);
+    const int pos0 = srt_xcd_order(nsp * nmb * nstem * ngrp * ksplit);
     SrtBlockCoord c;
+    c.ks = pos0 % ksplit;
+    const int pos = pos0 / ksplit;
     c.sp = pos % nsp;
     const int t = pos / nsp;
     c.grp = t % ngrp;

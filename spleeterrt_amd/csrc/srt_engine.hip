@@ -85,6 +85,7 @@ struct srt_engine {
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
     size_t raw_tile[6], up_tile[6];                    // floats per instance
+    float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     // DSP
     float *preWin, *postWin; float2* twiddle;
     float2* spec; float2* spec2; float* mag; float* masks; float* frames;   // spec2: residual spectrum of the CLI chain (on first use)
@@ -134,6 +135,7 @@ static void free_all(srt_engine* e)
     free_staging(e);
     if (e->coeff_all) hipFree(e->coeff_all);
     for (int i = 0; i < 6; ++i) { if (e->wpack16_down[i]) hipFree(e->wpack16_down[i]); if (e->wpack16_up[i]) hipFree(e->wpack16_up[i]); }
+    if (e->ws) hipFree(e->ws);
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
@@ -153,6 +155,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "srtCreate: no HIP device (this library has no CPU path)");
     srt_engine* e = new srt_engine();
     memset(&e->hs, 0, sizeof e->hs);
+    e->ws = nullptr; e->ws_floats = 0;
     if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail(-3, "srtCreate: no current HIP device"); }
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
@@ -281,6 +284,14 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     for (int s = s0; s < s0 + ns; ++s) if (!e->have_coeff[s]) return fail(-5, "srtForward: weights not set for every stem");
     const size_t HW = (size_t)T * F;
     e->last_ntiles = ntiles;
+    // Small batches (the real-time plugin: 1 tile x 4 stems; BASELINE configs[1]: 1 x 2) leave most CUs idle in the deep layers:
+    // give the launchers a workspace so they can cut those layers' K loops into slices (srt_nn2.hip, split-K).
+    if (!e->ws && (size_t)ns * ntiles <= 16 && e->cfg.impl == SRT_IMPL_MFMA && e->cfg.precision == SRT_PREC_F32) {
+        const size_t want = (size_t)16 << 20;              // 64 MiB: 8 slices of the largest split layer at 8 instances
+        if (hipMalloc((void**)&e->ws, want * sizeof(float)) == hipSuccess) e->ws_floats = want;
+        else { e->ws = nullptr; (void)hipGetLastError(); }
+    }
+    const bool small = e->ws && (size_t)ns * ntiles <= 16;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
         unsigned elu_mask = 0;
@@ -307,6 +318,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.outRaw = e->raw[i] + (size_t)s0 * ntiles * e->raw_tile[i];
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
+            if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
             if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
                 p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
                 if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
@@ -342,6 +354,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.outAct = e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
             p.out_stem = (size_t)ntiles * e->up_tile[i]; p.out_tile = e->up_tile[i];
             p.act = actD; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
+            if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
             if (i == 4) { p.wpack2 = e->wpack2_u5 + (size_t)s0 * 64 * 15 * 32; p.wpack2_stem = 64 * 15 * 32; p.CP2 = 32; }
             snprintf(nm, sizeof nm, "up%d", i + 1);
             TimerScope ts(e, nm);

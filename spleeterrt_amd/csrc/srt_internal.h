@@ -47,6 +47,11 @@ struct SrtConvParams {
     // fp16-MFMA variant (srt_nn3.hip): [Cin/16][25][2][CP][8] IEEE halves (k-group of 8 channels innermost)
     const uint16_t* wpack16; size_t wpack16_stem;
     int nsplit;           // 1: activations rounded to fp16; 2: activations split hi+lo (two MFMAs per tap, ~fp32 products)
+    // Split-K for small batches (srt_nn2.hip): when a layer's grid would leave most of the 256 CUs idle, its K loop (input
+    // channels) is cut into `ksplit` slices that run as separate workgroups; each writes its partial sums to
+    // ws[slice][same offsets as the output tensor] and srt_splitk_reduce adds the slices in slice order (bit-stable run to
+    // run) and applies the layer's epilogue.  The launcher picks ksplit; ws_floats = capacity of ws (0: never split).
+    float* ws; size_t ws_floats; int ksplit; size_t ws_slice;
     float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
     float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)
     size_t out_stem, out_tile;

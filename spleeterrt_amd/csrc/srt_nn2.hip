@@ -91,7 +91,32 @@ __device__ __forceinline__ void srt_mfma_pipeline()
     }
 }
 
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0>
+// The same with VALU groups woven into the second part of the chunk body: NV VALU instructions after every M1 + M2 MFMAs
+// once VSTART MFMAs have been issued.  Used by the variant that applies the input batch-norm + activation to the PREFETCHED
+// registers of the next chunk while this chunk's MFMAs run: each VALU group fits in the issue shadow of the wave's own MFMA,
+// and it starts late enough for the prefetch to have landed (the first group carries the s_waitcnt vmcnt).
+template <int NMFMA, int PRO, int M1, int M2, int NV, int VSTART>
+__device__ __forceinline__ void srt_mfma_pipeline_valu()
+{
+#pragma unroll
+    for (int i = 0; i < PRO; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int i = 0; i < NMFMA / (M1 + M2); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, M1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, M2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i * (M1 + M2) >= VSTART) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+}
+
+// ABL (SRT_TUNING builds only; 0 = the shipped kernel): 1,3,4,5,7,8 timing ablations (wrong results);
+//   15 = no s_setprio around the staging phase (the shipped kernel raises the priority while a wave stages its patch)
+//   11 = the input BN + activation is applied to the prefetched registers INSIDE the MFMA phase (VALU groups woven between MFMAs)
+//   12 = the same as one fenced burst after 40 % of the chunk's MFMAs
+//   13 = fenced, one staged float4 (4 values) at a time, spread over the remaining 60 %
+//   14 = fenced, one value at a time (~12 VALU: fits the issue shadow of the wave's own previous MFMA)
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0, bool SPLITK = false>
 __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
@@ -104,9 +129,13 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     constexpr int NF4 = KC * NI * PH * RW4, NLD = (NF4 + 255) / 256;
     constexpr int WROWS = KC * 25, WSLAB = (WROWS * BM + 255) / 256 * 256;
 
-    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
-    __shared__ float s_epi[BM];                         // bias of this workgroup's BM rows (see the epilogue)
-    __shared__ float s_ibn[2 * SRT_ENC_MAX_CIN];        // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
+    // ONE LDS object per kernel.  With a second __shared__ array the LDS lowering tags every access with alias scopes, and the
+    // waitcnt pass then puts an s_waitcnt vmcnt(0) in front of the first ds_read that follows a global_load_lds into the same
+    // object - i.e. at the TOP of the MFMA block, so the weight DMA and the patch prefetch of chunk ch+1 were waited for before
+    // the MFMAs of chunk ch instead of running under them (this was the "fixed cost" of every encoder layer: 10-15 %).
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + BM + 2 * SRT_ENC_MAX_CIN];
+    float* s_epi = s_mem + KC * CHS + 2 * WSLAB;        // bias of this workgroup's BM rows (see the epilogue)
+    float* s_ibn = s_epi + BM;                          // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
 
@@ -117,7 +146,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
     const int mtot = STEMSTACK ? p.stack * p.Cout : p.Cout;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (mtot + BM - 1) / BM, STEMSTACK ? 1 : p.nstems, groups);
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (mtot + BM - 1) / BM, STEMSTACK ? 1 : p.nstems, groups, SPLITK ? p.ksplit : 1);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
@@ -148,6 +177,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // Padding stays exactly zero (the select comes after the transform).  The constants are chunk-uniform per staged
     // element (its channel is fixed, only the chunk base moves) and sit in LDS.
     const bool xform = !STEMSTACK && p.inScale != nullptr;
+    constexpr bool XF_LOOP = !STEMSTACK && ABL >= 11 && ABL <= 14;        // transform inside the MFMA phase (launcher guarantees inScale)
     float4 pin[NLD];
     auto load_patch = [&](int c0) {
         const float* base = srcBase + (size_t)c0 * hw;
@@ -158,16 +188,59 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         }
     };
     auto store_patch = [&](int c0) {
+        if (xform && !XF_LOOP) {                                               // one uniform ELU / non-ELU branch around all NLD elements
+            float sc[NLD], sf[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const bool ok = goff[i] >= 0;                                  // padding: scale = shift = 0 -> act(0) = 0
+                const float a = s_ibn[c0 + cix[i]], b = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
+                sc[i] = ok ? a : 0.0f; sf[i] = ok ? b : 0.0f;
+            }
+            if (actp.ue != 0.0f) {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    pin[i].x = srt_act_apply(srt_bn(pin[i].x, sc[i], sf[i]), actp); pin[i].y = srt_act_apply(srt_bn(pin[i].y, sc[i], sf[i]), actp);
+                    pin[i].z = srt_act_apply(srt_bn(pin[i].z, sc[i], sf[i]), actp); pin[i].w = srt_act_apply(srt_bn(pin[i].w, sc[i], sf[i]), actp);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    pin[i].x = srt_act_lin(srt_bn(pin[i].x, sc[i], sf[i]), actp); pin[i].y = srt_act_lin(srt_bn(pin[i].y, sc[i], sf[i]), actp);
+                    pin[i].z = srt_act_lin(srt_bn(pin[i].z, sc[i], sf[i]), actp); pin[i].w = srt_act_lin(srt_bn(pin[i].w, sc[i], sf[i]), actp);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (loff[i] >= 0) {
-                float4 v = pin[i];
-                if (xform) v = srt_enc_input4(v, s_ibn[c0 + cix[i]], s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]], goff[i] >= 0, actp);
+                const float4 v = pin[i];
                 float* d = s_in + loff[i];
                 *reinterpret_cast<float2*>(d) = make_float2(v.x, v.z);            // even columns -> plane 0
                 *reinterpret_cast<float2*>(d + PWH) = make_float2(v.y, v.w);      // odd columns  -> plane 1
             }
         }
+    };
+
+    // branch-free (the chunk body must stay one basic block for the scheduling groups): the exp is evaluated for every stem kind
+    auto xform_pin = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool ok = goff[i] >= 0;                                      // padding: scale = shift = 0 -> act(0) = 0
+            const float sc0 = s_ibn[c0 + cix[i]], sf0 = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
+            const float sc = ok ? sc0 : 0.0f, sf = ok ? sf0 : 0.0f;
+            pin[i].x = srt_enc_epilogue(pin[i].x, sc, sf, actp);
+            pin[i].y = srt_enc_epilogue(pin[i].y, sc, sf, actp);
+            pin[i].z = srt_enc_epilogue(pin[i].z, sc, sf, actp);
+            pin[i].w = srt_enc_epilogue(pin[i].w, sc, sf, actp);
+        }
+    };
+
+    auto xform_comp = [&](int i, int comp, int c0) {       // one staged value (compile-time i, comp)
+        const bool ok = goff[i] >= 0;
+        const float sc0 = s_ibn[c0 + cix[i]], sf0 = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
+        const float sc = ok ? sc0 : 0.0f, sf = ok ? sf0 : 0.0f;
+        float& x = comp == 0 ? pin[i].x : (comp == 1 ? pin[i].y : (comp == 2 ? pin[i].z : pin[i].w));
+        x = srt_enc_epilogue(x, sc, sf, actp);
     };
 
     f32x16 acc[MR][NR];
@@ -204,14 +277,27 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
         }
         __syncthreads();
     }
-    const int nchunks = p.Cin / KC;
-    srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
-    load_patch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+    // split-K: this workgroup runs the chunks [chA, chB) of the K loop (all of them in a plain launch)
+    const int nchunks_all = p.Cin / KC;
+    const int cps = SPLITK ? (nchunks_all + p.ksplit - 1) / p.ksplit : nchunks_all;
+    const int chA = SPLITK ? bc.ks * cps : 0, nchunks = SPLITK ? min(nchunks_all, chA + cps) : nchunks_all;
+    srt_dma_slab<WROWS, BM>(wp + (size_t)chA * KC * 25 * CPW, CPW, s_w + (chA & 1) * WSLAB, wave, lane);
+    load_patch(chA * KC);
+    if (XF_LOOP) xform_pin(chA * KC);
+    for (int ch = chA; ch < nchunks; ++ch) {
+        // A wave that stages (input BN + activation, LDS stores) outranks the co-resident workgroup's MFMA stream for VALU issue:
+        // the staging phase sits between two barriers, so every cycle it loses to the other workgroup delays all four waves
+        // (measured: down4-down6 1.5-4.5 % faster, nothing slower; ABL 15 = without).
+        if (ABL != 15) __builtin_amdgcn_s_setprio(3);
         if ((ABL != 1 && ABL != 4) || ch == 0) store_patch(ch * KC);
         __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
+        if (ABL != 15) __builtin_amdgcn_s_setprio(0);
         const float* sw = s_w + (ch & 1) * WSLAB;
-        if (ch + 1 < nchunks && ABL != 1) {       // issued up front; spreading the pieces between the MFMAs measured no gain
+        const int cn = min(ch + 1, nchunks - 1);           // XF_LOOP: unconditional prefetch (a redundant reload at the end) keeps the body branch-free
+        if (XF_LOOP) {
+            srt_dma_slab<WROWS, BM>(wp + (size_t)cn * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
+            load_patch(cn * KC);
+        } else if (ch + 1 < nchunks && ABL != 1) {       // issued up front; spreading the pieces between the MFMAs measured no gain
             if (ABL != 5) srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
             if (ABL != 4) load_patch((ch + 1) * KC);
         }
@@ -230,9 +316,30 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+                if (ABL >= 12 && ABL <= 14) {
+                    constexpr int NSTEP = (KC / 2) * 25, K0 = NSTEP * 2 / 5, NCOMP = 4 * NLD;
+                    constexpr int PER = ABL == 12 ? NCOMP : (ABL == 13 ? 4 : 1);          // values transformed per insertion point
+                    constexpr int NPT = NCOMP / PER, STRIDE = (NSTEP - 1 - K0) / NPT > 0 ? (NSTEP - 1 - K0) / NPT : 1;
+                    const int k = cp * 25 + tap;
+                    if (k >= K0 && (k - K0) % STRIDE == 0 && (k - K0) / STRIDE < NPT) {
+                        const int pt = (k - K0) / STRIDE;
+                        __builtin_amdgcn_sched_barrier(0x3F4);                             // memory + SALU may cross, VALU / MFMA stay put
+#pragma unroll
+                        for (int q = pt * PER; q < pt * PER + PER; ++q) xform_comp(q / 4, q % 4, cn * KC);
+                        __builtin_amdgcn_sched_barrier(0x3F4);
+                    }
+                }
             }
         }
-        if (ABL == 0) srt_mfma_pipeline<(KC / 2) * 25 * MR * NR, 16, 1, 2>();
+        if (ABL == 11) {
+            xform_pin(cn * KC);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)                  // keep the transform on this side of the barrier (LLVM sinks it to its use otherwise)
+                asm volatile("" : "+v"(pin[i].x), "+v"(pin[i].y), "+v"(pin[i].z), "+v"(pin[i].w));
+            constexpr int NM = (KC / 2) * 25 * MR * NR;
+            srt_mfma_pipeline_valu<NM, 16, 1, 2, (NLD * 4 * 12 + (NM * 3 / 5) / 3 - 1) / ((NM * 3 / 5) / 3), NM * 2 / 5>();
+        }
+        if (ABL == 0 || ABL == 15) srt_mfma_pipeline<(KC / 2) * 25 * MR * NR, 16, 1, 2>();
         __syncthreads();                                   // everyone is done with s_in and slab (ch&1)
     }
 
@@ -261,7 +368,10 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pix_ok && m < mlimit) p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
+                if (pix_ok && m < mlimit) {
+                    if (SPLITK) p.ws[(size_t)bc.ks * p.ws_slice + ob[r] + pbase] = acc[mr][nr][r];      // partial sum; bias is added by the reduce
+                    else p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
+                }
             }
         }
     }
@@ -269,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
 
 // ------------------------------------------------------------------------------------------- decoder v2
 // CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0>
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0, bool SPLITK = false>
 __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
@@ -291,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     const int wm = wave % WM, wn = wave / WM;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, CLASSSTACK ? 1 : (p.Cout + BM - 1) / BM, p.nstems, groups);
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, CLASSSTACK ? 1 : (p.Cout + BM - 1) / BM, p.nstems, groups, SPLITK ? p.ksplit : 1);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
@@ -352,10 +462,12 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     }
     const int aoff = half * NTAP * BM + wm * MR * 32 + l31;
 
-    const int nchunks = p.Cin / KC;
-    srt_dma_slab<WROWS, BM>(wp, CPW, s_w, wave, lane);
-    load_patch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+    const int nchunks_all = p.Cin / KC;                    // split-K: chunks [chA, nchunks) of the K loop (see srt_enc_mfma2)
+    const int cps = SPLITK ? (nchunks_all + p.ksplit - 1) / p.ksplit : nchunks_all;
+    const int chA = SPLITK ? bc.ks * cps : 0, nchunks = SPLITK ? min(nchunks_all, chA + cps) : nchunks_all;
+    srt_dma_slab<WROWS, BM>(wp + (size_t)chA * KC * NTAP * CPW, CPW, s_w + (chA & 1) * WSLAB, wave, lane);
+    load_patch(chA * KC);
+    for (int ch = chA; ch < nchunks; ++ch) {
         if ((ABL != 1 && ABL != 4) || ch == 0) store_patch();
         if (ABL != 2) __syncthreads();
         const float* sw = s_w + (ch & 1) * WSLAB;
@@ -440,9 +552,14 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 #pragma unroll
                         for (int py = 0; py < 2; ++py) {
                             float2 v;
-                            v.x = srt_dec_epilogue(acc[(py * 2 + 0) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
-                            v.y = srt_dec_epilogue(acc[(py * 2 + 1) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
-                            *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                            if (SPLITK) {                                  // partial sums; bias -> act -> BN happen in the reduce
+                                v.x = acc[(py * 2 + 0) % NCLS][mr][nr][r]; v.y = acc[(py * 2 + 1) % NCLS][mr][nr][r];
+                                *reinterpret_cast<float2*>(p.ws + (size_t)bc.ks * p.ws_slice + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                            } else {
+                                v.x = srt_dec_epilogue(acc[(py * 2 + 0) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
+                                v.y = srt_dec_epilogue(acc[(py * 2 + 1) % NCLS][mr][nr][r], bi[r], sc[r], sf[r], actp);
+                                *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                            }
                         }
                     }
                 }
@@ -585,7 +702,84 @@ __global__ void __launch_bounds__(256, 2) srt_dec16_kernel(const SrtConvParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------- split-K reduce
+// out[e] = epilogue(sum over slices k = 0..ksplit-1 of ws[k][e]), slices added in ascending order (the same bits every run).
+// Encoder: conv + bias (the raw tensor).  Decoder: bn(act(sum + bias)).  One float4 per thread; a float4 never straddles a
+// channel plane (plane sizes are multiples of 4 here: the v2 kernels require W % 4 == 0).
+template <bool DEC>
+__global__ void __launch_bounds__(256) srt_splitk_reduce(const SrtConvParams p, size_t plane, size_t total)
+{
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= total) return;
+    const int stem = (int)(e / p.out_stem);
+    const int ch = (int)(((e % p.out_stem) % p.out_tile) / plane);
+    float4 a = *reinterpret_cast<const float4*>(p.ws + e);
+    for (int k = 1; k < p.ksplit; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(p.ws + (size_t)k * p.ws_slice + e);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const size_t ci = stem * p.coeff_stem + ch;
+    const float bi = p.bias[ci];
+    if (DEC) {
+        const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+        const float sc = p.bnScale[ci], sf = p.bnShift[ci];
+        a.x = srt_dec_epilogue(a.x, bi, sc, sf, actp); a.y = srt_dec_epilogue(a.y, bi, sc, sf, actp);
+        a.z = srt_dec_epilogue(a.z, bi, sc, sf, actp); a.w = srt_dec_epilogue(a.w, bi, sc, sf, actp);
+        *reinterpret_cast<float4*>(p.outAct + e) = a;
+    } else {
+        a.x += bi; a.y += bi; a.z += bi; a.w += bi;
+        *reinterpret_cast<float4*>(p.outRaw + e) = a;
+    }
+}
+
+// How many K slices a launch of `base` workgroups over `nchunks` chunks should be cut into: enough to give every CU work,
+// at least two chunks per slice (prologue / epilogue would dominate otherwise), and no more than the workspace holds.
+static int srt_pick_ksplit(const SrtConvParams& p, long base, int nchunks, size_t out_floats)
+{
+    if (!p.ws || base >= 192 || nchunks < 4 || out_floats % 4) return 1;
+    long ks = (256 + base - 1) / base;
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    while (ks > 1 && (size_t)ks * out_floats > p.ws_floats) --ks;
+    return ks < 1 ? 1 : (int)ks;
+}
+
+template <int BM, int WM, int SW, int NSX, int NSY, int KC>
+static int launch_enc2_splitk(const SrtConvParams& p0, int ks, hipStream_t s)      // NI = 1: small batches have no instances to spare
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    SrtConvParams p = p0;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    p.ksplit = ks; p.ws_slice = (size_t)p.nstems * p.out_stem;
+    dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.Cout + BM - 1) / BM) * p.nstems * p.ntiles * ks);
+    hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, 1, KC, false, 0, true>), grid, dim3(256), 0, s, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+    const size_t total = p.ws_slice;
+    hipLaunchKernelGGL(srt_splitk_reduce<false>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, p, (size_t)Ho * Wo, total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int BM, int WM, int SW, int NSX, int NSY, int KC>
+static int launch_dec2_splitk(const SrtConvParams& p0, int ks, hipStream_t s)
+{
+    constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
+    SrtConvParams p = p0;
+    p.ksplit = ks; p.ws_slice = (size_t)p.nstems * p.out_stem;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + BM - 1) / BM) * p.nstems * p.ntiles * ks);
+    hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, 1, KC, false, 0, true>), grid, dim3(256), 0, s, p);
+    if (hipGetLastError() != hipSuccess) return -1;
+    const size_t total = p.ws_slice;
+    hipLaunchKernelGGL(srt_splitk_reduce<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, p, (size_t)4 * p.H * p.W, total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// base workgroup count of a plain launch with NI = 1 (what split-K multiplies)
+static long srt_base_wgs(const SrtConvParams& p, int H, int W, int TH, int TW, int BM)
+{
+    return (long)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * ((p.Cout + BM - 1) / BM) * p.nstems * p.ntiles;
+}
+
 // ------------------------------------------------------------------------------------------- dispatch
+#ifdef SRT_TUNING
+static int tune(const char* key);
+#endif
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
 {
@@ -593,6 +787,17 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
     const int Ho = p.H / 2, Wo = p.W / 2;
     const int mtot = STK ? p.stack * p.Cout : p.Cout;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((mtot + BM - 1) / BM) * (STK ? 1 : p.nstems) * ((p.ntiles + NI - 1) / NI));
+#ifdef SRT_TUNING
+    if constexpr (!STK) if (p.inScale) {                  // where the input BN + activation runs: encx = 11..15 (see srt_enc_mfma2)
+        switch (tune("encx")) {
+        case 15: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 15>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 11: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 11>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 12: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 12>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 13: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 13>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 14: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 14>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
+#endif
     hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -658,6 +863,24 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 #endif
         return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 2, true>(p, s);
     }
+    // small batches: cut the K loop so that every CU gets a workgroup (instances x stems <= ~8; never taken by the 64-tile batches)
+    {
+        const int Ho = p.H / 2;
+        const size_t outf = (size_t)p.nstems * p.out_stem;
+        if (p.Cout <= 32) {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 32), p.Cin / 2, outf);
+            if (ks > 1) return launch_enc2_splitk<32, 1, 32, 2, 4, 2>(p, ks, s);
+        } else if (Wo >= 64) {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 64), p.Cin / 4, outf);
+            if (ks > 1) return launch_enc2_splitk<64, 2, 32, 2, 4, 4>(p, ks, s);
+        } else if (Wo >= 32) {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 8, 32, 64), p.Cin / 4, outf);
+            if (ks > 1) return launch_enc2_splitk<64, 2, 32, 1, 8, 4>(p, ks, s);
+        } else {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 16, 64), p.Cin / 4, outf);
+            if (ks > 1) return launch_enc2_splitk<64, 2, 16, 1, 2, 4>(p, ks, s);
+        }
+    }
     if (p.Cout <= 32) {                                                                  // down2 (an 8x64 tile / NR = 4 measured 4 % slower)
 #ifdef SRT_TUNING
         switch (tune("down2")) {
@@ -711,6 +934,19 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
 #endif
         hipLaunchKernelGGL((srt_dec16_kernel<4, 4, 4>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    {                                                                                    // small batches: split-K (see srt_launch_enc2)
+        const size_t outf = (size_t)p.nstems * p.out_stem;
+        if (p.Cout <= 32) {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 64, 32), p.Cin / 4, outf);
+            if (ks > 1) return launch_dec2_splitk<32, 1, 32, 2, 4, 4>(p, ks, s);
+        } else if (p.W >= 32) {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 32, 64), p.Cin / 4, outf);
+            if (ks > 1) return launch_dec2_splitk<64, 2, 32, 1, 4, 4>(p, ks, s);
+        } else {
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 16, 64), p.Cin / 4, outf);
+            if (ks > 1) return launch_dec2_splitk<64, 2, 16, 1, 2, 4>(p, ks, s);
+        }
     }
     if (p.Cout <= 32) {                                                                  // up4 (KC = 8 measured 5 % slower)
 #ifdef SRT_TUNING

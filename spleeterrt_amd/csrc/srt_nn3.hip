@@ -230,10 +230,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     constexpr int ROWS = 2 * PWH, PLANE = NI * PH * ROWS * 8;
     constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
     constexpr int WSLAB = 25 * 512;
-    __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
-    __shared__ float s_epi[32];                             // bias of the 32 rows, staged before the K loop (see srt_enc_mfma2)
-    __shared__ float s_ibn[2 * SRT_ENC_MAX_CIN];            // BN scale | shift of the input channels (applied while staging)
-    static_assert(sizeof(_Float16) * (NSPLIT * 2 * PLANE + 2 * WSLAB) + (32 + 2 * SRT_ENC_MAX_CIN) * sizeof(float) <= 160 * 1024, "LDS");
+    // one LDS object (see srt_enc_mfma2: a second __shared__ array makes the compiler wait for the weight DMA before the MFMAs)
+    constexpr int NCONST = 32 + 2 * SRT_ENC_MAX_CIN;        // floats: bias of the 32 rows | BN scale | BN shift of the input channels
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB + 2 * NCONST];
+    static_assert(sizeof(s_mem) <= 160 * 1024 && (NSPLIT * 2 * PLANE + 2 * WSLAB) % 8 == 0, "LDS");
+    float* s_epi = reinterpret_cast<float*>(s_mem + NSPLIT * 2 * PLANE + 2 * WSLAB);
+    float* s_ibn = s_epi + 32;
     _Float16* s_in = s_mem;
     _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
 
@@ -281,7 +283,11 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float4 pv = pin[i][q];
-                    if (xform) { const int c = cg * 16 + gg * 8 + q; pv = srt_enc_input4(pv, s_ibn[c], s_ibn[SRT_ENC_MAX_CIN + c], ok, actp); }
+                    if (xform) {
+                        const int c = cg * 16 + gg * 8 + q;
+                        const float sc = s_ibn[c], sf = s_ibn[SRT_ENC_MAX_CIN + c];
+                        pv = srt_enc_input4(pv, ok ? sc : 0.0f, ok ? sf : 0.0f, actp);      // padding: scale = shift = 0 -> act(0) = 0
+                    }
                     const float x[4] = { pv.x, pv.y, pv.z, pv.w };
 #pragma unroll
                     for (int px = 0; px < 4; ++px) {
