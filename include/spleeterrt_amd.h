@@ -105,6 +105,13 @@ SRT_API int  srtSeparateHostStreamEx(srt_engine *e, const float *h_L, const floa
 SRT_API int  srtSeparateCli(srt_engine *e, const float *d_L, const float *d_R, size_t n, int stems, float *d_out);
 SRT_API int  srtSeparateCliHost(srt_engine *e, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);  /* host buffers, synchronous */
 
+/* Low-latency callers that repeat the same call (same device pointers and sizes) over and over - the real-time plugin, the tile
+ * API on one pair of buffers: with graph mode on, srtForward and srtSeparate / srtSeparateEx capture their launch sequence into
+ * a hipGraph the first time an argument tuple is seen and replay it afterwards (one host call instead of ~25 launches; 4 cached
+ * tuples, least recently used evicted).  Needs an explicit stream (the legacy null stream cannot be captured: the engine then
+ * keeps launching eagerly).  Results are identical either way.  Off by default. */
+SRT_API int  srtSetGraphMode(srt_engine *e, int enable);
+
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */
 SRT_API int  srtSetTiming(srt_engine *e, int enable);                    /* record HIP events around every launch of the next calls */

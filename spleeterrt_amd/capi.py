@@ -60,6 +60,7 @@ def load_library():
     L.srtStftEx.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p]
     L.srtSeparateEx.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
     L.srtCopyTensor.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
+    L.srtSetGraphMode.argtypes = [vp, C.c_int]
     L.srtSetTiming.argtypes = [vp, C.c_int]
     L.srtGetTiming.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
     _lib = L
@@ -241,6 +242,10 @@ class Engine:
         a = np.empty(sh, np.float32)
         self._chk(self.L.srtCopyTensor(self.h, name.encode(), stem, tile, C.c_void_p(a.ctypes.data), a.size))
         return a
+
+    def set_graph_mode(self, on=True):
+        """replay srtForward / srtSeparate as captured hipGraphs when called again with the same tensors (needs a non-default stream)"""
+        self._chk(self.L.srtSetGraphMode(self.h, int(on)))
 
     def set_timing(self, on=True):
         self._chk(self.L.srtSetTiming(self.h, int(on)))

@@ -72,6 +72,7 @@ void initSpleeter(struct _spleeter* nn, size_t width, size_t height, int stemMod
     if (!hip_ok(hipStreamCreateWithFlags(&nn->stream, hipStreamNonBlocking), "initSpleeter")) { nn->stream = nullptr; return; }
     if (srtCreate(&cfg, nn->stream, &nn->eng)) { nn->eng = nullptr; compat_fail("initSpleeter", nullptr); return; }
     if (srtSetCoeffHost(nn->eng, 0, coeff)) { compat_fail("initSpleeter(weights)", nullptr); return; }
+    srtSetGraphMode(nn->eng, 1);                              // every processSpleeter call repeats the same launch sequence on d_x / d_y
     if (!hip_ok(hipMalloc((void**)&nn->d_x, nn->hw2 * sizeof(float)), "initSpleeter")) { nn->d_x = nullptr; return; }
     if (!hip_ok(hipMalloc((void**)&nn->d_y, nn->hw2 * sizeof(float)), "initSpleeter")) { nn->d_y = nullptr; return; }
     nn->failed = 0;

@@ -84,6 +84,15 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
 }
 #pragma clang fp contract(fast)
 
+// element-typed view of the same selection (T = _Float16 when the source tensors are stored as halves: strides are in elements)
+template <class T>
+__device__ __forceinline__ const T* srt_src_channel_t(const SrtConvParams& p, int stem, int tile, int ch, size_t hw)
+{
+    const bool a = ch < p.CA;
+    const T* base = reinterpret_cast<const T*>(a ? p.srcA : p.srcB);
+    const size_t ss = a ? p.srcA_stem : p.srcB_stem, ts = a ? p.srcA_tile : p.srcB_tile;
+    return base + stem * ss + tile * ts + (size_t)(a ? ch : ch - p.CA) * hw;
+}
 __device__ __forceinline__ const float* srt_src_channel(const SrtConvParams& p, int stem, int tile, int ch, size_t hw)
 {
     const bool a = ch < p.CA;

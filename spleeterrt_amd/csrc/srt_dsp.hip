@@ -138,15 +138,56 @@ __device__ __forceinline__ void fft4096(cf (&v)[16], cf* s, const cf* tw, int ti
     fft16(v);                                            // over n0 -> k2
 }
 
-#define STFT_FPB 8      // frames per workgroup (amortises the twiddle-table load; consecutive frames share 75% of input)
-
-__global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
+// The same transform for kernels that walk MANY frames per workgroup, with half the barriers: the 15 pass-1 twiddles of a thread
+// are frame independent and live in registers (twa), which shrinks the LDS twiddle table to the 240 pass-2 entries and makes
+// room for TWO exchange buffers.  With exchange 1 in one buffer and exchange 2 in the other no barrier is needed between
+// reading an exchange and writing the next one:
+//   in : v[n2] = x[tid + 256*n2], read by every thread from buffer `e2` (or from registers) AFTER a barrier that follows the
+//        last use of buffer `e1` by the previous frame
+//   out: v[FFT16_AT(k2)] = X[tid + 256*k2]; `e1` is free again, `e2` still holds exchange 2 until the caller's next barrier
+// A frame then costs 3 barriers (staging, exchange 1, exchange 2) instead of 6.
+#define FFT_TWB_F2 240
+__device__ __forceinline__ void fft_load_twiddles_pp(cf (&twa)[15], cf* twb, const float2* __restrict__ table_f2, int tid)
 {
-    __shared__ cf s_tw[FFT_TW_F2];
-    __shared__ cf s_x[FFT_SMEM_F2];
+    const cf* __restrict__ table = reinterpret_cast<const cf*>(table_f2);
+#pragma unroll
+    for (int k0 = 1; k0 < 16; ++k0) twa[k0 - 1] = table[(tid * k0) & 4095];
+    if (tid < FFT_TWB_F2) twb[tid] = table[(16 * (tid & 15) * (tid / 16 + 1)) & 4095];
+}
+__device__ __forceinline__ void fft4096_pp(cf (&v)[16], cf* e1, cf* e2, const cf (&twa)[15], const cf* twb, int tid)
+{
+    fft16(v);                                            // over n2 -> k0
+#pragma unroll
+    for (int k0 = 1; k0 < 16; ++k0) v[FFT16_AT(k0)] = cmul(v[FFT16_AT(k0)], twa[k0 - 1]);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) e1[k0 * FFT_EX1_LD + tid] = v[FFT16_AT(k0)];
+    __syncthreads();
+    const int lo = tid & 15, hi = tid >> 4;              // (n0, k0)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = e1[hi * FFT_EX1_LD + n1 * 16 + lo];
+    fft16(v);                                            // over n1 -> k1
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[FFT16_AT(k1)] = cmul(v[FFT16_AT(k1)], twb[(k1 - 1) * 16 + lo]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) e2[lo * FFT_EX2_LD + k1 * 16 + hi] = v[FFT16_AT(k1)];
+    __syncthreads();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = e2[n0 * FFT_EX2_LD + tid];   // tid = k0 + 16*k1
+    fft16(v);                                            // over n0 -> k2
+}
+
+#define STFT_FPB 8      // frames per workgroup on long signals (amortises the twiddle-table load; consecutive frames share 75% of input)
+
+__global__ void __launch_bounds__(256, 2) srt_stft_kernel(const SrtStftParams p, int fpb)
+{
+    __shared__ cf s_mem[2 * FFT_SMEM_F2 + FFT_TWB_F2];   // two exchange buffers + the pass-2 twiddles (one LDS object)
+    cf* bufA = s_mem;
+    cf* bufB = s_mem + FFT_SMEM_F2;
+    cf* s_twb = s_mem + 2 * FFT_SMEM_F2;
     const int tid = threadIdx.x;
     const int blk = blockIdx.x;                          // (XCD order measured no better here: the input is 8 KB per frame)
-    fft_load_twiddles(s_tw, p.tab.twiddle, tid);
+    cf twa[15];
+    fft_load_twiddles_pp(twa, s_twb, p.tab.twiddle, tid);
     __syncthreads();
 
     // the windowed samples of the NEXT frame are loaded while the current frame is transformed (clamped frame index:
@@ -166,9 +207,11 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
         }
     };
     const int flast = max(p.frames_computed, 1) - 1;
-    fetch(min((int)(blk * STFT_FPB), flast));
-    for (int fi = 0; fi < STFT_FPB; ++fi) {
-        const int f = blk * STFT_FPB + fi;
+    cf* e1 = bufA;
+    cf* e2 = bufB;
+    fetch(min((int)(blk * fpb), flast));
+    for (int fi = 0; fi < fpb; ++fi) {
+        const int f = blk * fpb + fi;
         if (f >= p.rows_total) break;
         const int tile = f / p.T, t = f % p.T;
         float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
@@ -184,17 +227,22 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) v[n2] = nxt[n2];
         fetch(min(f + 1, flast));
-        fft4096(v, s_x, s_tw, tid);
-        __syncthreads();
+        // exchange 1 in e1, exchange 2 in e2, natural-order result back in e1 (free once exchange 1 has been read).  The two
+        // buffers swap roles every frame: the next frame's exchange 1 goes where this frame's exchange 2 was (all of its reads
+        // precede the barrier below), and its exchange 2 - written behind the transform's first barrier - goes where this
+        // frame's epilogue reads from.
+        fft4096_pp(v, e1, e2, twa, s_twb, tid);
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) s_x[tid + 256 * k2] = v[FFT16_AT(k2)];
+        for (int k2 = 0; k2 < 16; ++k2) e1[tid + 256 * k2] = v[FFT16_AT(k2)];
         __syncthreads();
+        const cf* nat = e1;
+        { cf* t = e1; e1 = e2; e2 = t; }
         // separate the two real spectra; stored spectrum = conj(F) (the reference's re/im convention)
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = tid + 256 * j;
             if (k <= 2048) {
-                const cf zk = s_x[k], zm = s_x[(4096 - k) & 4095];
+                const cf zk = nat[k], zm = nat[(4096 - k) & 4095];
                 const cf sl = split_l(zk, zm), sr = split_r(zk, zm);
                 specL[k] = sl;
                 specR[k] = sr;
@@ -207,15 +255,16 @@ __global__ void __launch_bounds__(256) srt_stft_kernel(const SrtStftParams p)
                 specR[k] = f2(0.f, 0.f);
             }
         }
-        __syncthreads();
     }
 }
 
 int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
 {
-    const int blocks = (p.rows_total + STFT_FPB - 1) / STFT_FPB;
+    // short signals (one tile, the real-time regime): fewer frames per workgroup so that the frames spread over the CUs
+    const int fpb = p.rows_total >= 4096 ? STFT_FPB : (p.rows_total >= 1024 ? 2 : 1);
+    const int blocks = (p.rows_total + fpb - 1) / fpb;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -233,11 +282,13 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
     // 1-D launch in XCD order, stem fastest: the nstems workgroups that walk the SAME run of frames sit next to each other on
     // one XCD, so the spectrum rows the first of them pulls from HBM are L2 hits for the others (each stem re-read them before).
     const int pos = srt_xcd_order(gridDim.x), stem = pos % p.nstems, run = pos / p.nstems;
-    __shared__ cf s_tw[FFT_TW_F2];
-    __shared__ cf s_x[FFT_SMEM_F2];
+    __shared__ cf s_mem[2 * FFT_SMEM_F2 + FFT_TWB_F2];   // two staging / exchange buffers + the pass-2 twiddles (one LDS object)
+    cf* sx = s_mem;                                      // this frame's staging buffer (and its exchange 2)
+    cf* sy = s_mem + FFT_SMEM_F2;                        // this frame's exchange 1; the roles swap every frame
+    cf* s_twb = s_mem + 2 * FFT_SMEM_F2;
     const int tid = threadIdx.x;
-    fft_load_twiddles(s_tw, p.tab.twiddle, tid);
-    __syncthreads();
+    cf twa[15];
+    fft_load_twiddles_pp(twa, s_twb, p.tab.twiddle, tid);
     const size_t tf = (size_t)p.T * p.F;
     const int nseg = p.frames + 3;
     const int s0 = run * G, s1 = min(s0 + G, nseg);
@@ -279,6 +330,8 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
     if (f0 < p.frames) fetch(f0);
     for (int f = f0; f < s1; ++f) {
         if (f < p.frames) {                             // workgroup-uniform; false only for the last three segments of the stream
+            // staging into sx: its last readers (exchange 1 of the previous frame, when it was `sy`) all passed that frame's
+            // second barrier; the first barrier below also orders the twiddle table written before the loop
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const int k = tid + 256 * j;
@@ -286,26 +339,27 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
                     const float wl = k < p.F ? (has_mask ? gl[j] : 1.0f) : oob, wr = k < p.F ? (has_mask ? gr[j] : 1.0f) : oob;
                     const cf A = sl[j] * wl, B = sr[j] * wr;                      // masked (re, im) of L and R
                     // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; stored swapped (im,re): inverse-by-forward trick
-                    if (k == 0) s_x[0] = f2(B.x, A.x);                            // a[0] = re[0]           (stftFix.c:556-557)
-                    else if (k == 2048) s_x[2048] = f2(B.x - B.y, A.x - A.y);    // rev[2048]: re - im wins (stftFix.c:563-566)
+                    if (k == 0) sx[0] = f2(B.x, A.x);                             // a[0] = re[0]           (stftFix.c:556-557)
+                    else if (k == 2048) sx[2048] = f2(B.x - B.y, A.x - A.y);     // rev[2048]: re - im wins (stftFix.c:563-566)
                     else {
-                        s_x[k] = sub_mi(B, A);                                    // (reR - imL, imR + reL)
-                        s_x[4096 - k] = herm_hi(B, A);                            // (reR + imL, reL - imR)
+                        sx[k] = sub_mi(B, A);                                     // (reR - imL, imR + reL)
+                        sx[4096 - k] = herm_hi(B, A);                             // (reR + imL, reL - imR)
                     }
                 }
             }
             __syncthreads();
             cf v[16];
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) v[n2] = s_x[tid + 256 * n2];
-            __syncthreads();
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = sx[tid + 256 * n2];
             fetch(min(f + 1, p.frames - 1));            // the staging registers are free again: next frame's rows fly under this FFT
-            fft4096(v, s_x, s_tw, tid);
+            // exchange 1 in sy (free: its previous contents, the previous frame's exchange 2, were read before the barrier above),
+            // exchange 2 back in sx (every thread has read its staged values before the transform's first barrier)
+            fft4096_pp(v, sy, sx, twa, s_twb, tid);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 acc[k2 >> 2][k2 & 3] = __builtin_elementwise_fma(v[FFT16_AT(k2)], f2(pw[k2], pw[k2]), acc[k2 >> 2][k2 & 3]);   // swapped back: L = .y, R = .x
             }
-            __syncthreads();
+            { cf* t = sx; sx = sy; sy = t; }            // next frame stages where this frame's exchange 1 was (read before the second barrier)
         }
         if (f >= s0) {                                  // segment f is complete: emit it
 #pragma unroll
@@ -325,7 +379,8 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     // One launch for all stems (blockIdx.y = stem): ~4 workgroups per CU over the whole grid when the stream is long enough,
     // runs of at least 13 segments so the 3-frame warm-up stays below ~25 % (64-tile batch, 4 stems: G = 65, 4.6 %).
     int G = (int)(((size_t)nseg * p.nstems + 1023) / 1024);
-    if (G < 13) G = 13;
+    const int gmin = (size_t)nseg * p.nstems >= 4096 ? 13 : 5;          // short signals: shorter runs (more warm-up, but all CUs busy)
+    if (G < gmin) G = gmin;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
     hipLaunchKernelGGL(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);

@@ -59,6 +59,13 @@ struct HostStaging {
     bool ready;
 };
 
+// hipGraph replay of the launch sequences a low-latency caller repeats with the same arguments (srtSetGraphMode): the real-time
+// plugin runs srtForward on the same two mask buffers for ever, the tile API on one pair of buffers.  A sequence is captured
+// the first time its argument tuple is seen and replayed afterwards: one host call instead of ~25 launches on the audio thread.
+struct GraphKey { int kind; const void* p0; const void* p1; void* p2; size_t n, frames, rows; int ntiles, s0, ns; };
+struct GraphSlot { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long used; };
+#define SRT_GRAPH_SLOTS 4
+
 // Every entry point that allocates or launches runs on the device the engine was created on, whatever the caller's
 // current device is (a host thread that switched devices after srtCreate must not mix device-A streams with device-B memory).
 struct DeviceScope {
@@ -85,7 +92,9 @@ struct srt_engine {
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
     size_t raw_tile[6], up_tile[6];                    // floats per instance
+    bool act16;                                        // raw[0..5] and up[0..4] hold IEEE halves (precision F16 on a supported geometry)
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
+    int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
     // DSP
     float *preWin, *postWin; float2* twiddle;
     float2* spec; float2* spec2; float* mag; float* masks; float* frames;   // spec2: residual spectrum of the CLI chain (on first use)
@@ -100,6 +109,9 @@ size_t srtCoeffBytes(void) { return (size_t)SRT_COEFF_FLOATS * 4; }
 size_t srtStftRows(size_t n) { return (n + SRT_HOP - 1) / SRT_HOP; }
 size_t srtStftFrames(size_t n) { return n < SRT_FFT ? 0 : (n - SRT_FFT + SRT_HOP / 4) / SRT_HOP + 1; }   // stftFix.c:378 + tail frame
 size_t srtIstftLength(size_t rows) { return rows * SRT_HOP + (SRT_FFT - SRT_HOP); }
+
+// element offset into an activation tensor whose elements are halves (act16) or floats
+static inline float* eoff(const srt_engine* e, float* base, size_t elems) { return (float*)((char*)base + elems * (e->act16 ? 2 : 4)); }
 
 struct TimerScope {
     srt_engine* e; size_t idx; bool on;
@@ -130,8 +142,18 @@ static void free_staging(srt_engine* e)
     memset(&h, 0, sizeof h);
 }
 
+static void free_graphs(srt_engine* e)
+{
+    for (GraphSlot& g : e->gslots) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+        memset(&g, 0, sizeof g);
+    }
+}
+
 static void free_all(srt_engine* e)
 {
+    free_graphs(e);
     free_staging(e);
     if (e->coeff_all) hipFree(e->coeff_all);
     for (int i = 0; i < 6; ++i) { if (e->wpack16_down[i]) hipFree(e->wpack16_down[i]); if (e->wpack16_up[i]) hipFree(e->wpack16_up[i]); }
@@ -156,6 +178,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     srt_engine* e = new srt_engine();
     memset(&e->hs, 0, sizeof e->hs);
     e->ws = nullptr; e->ws_floats = 0;
+    e->graph_mode = 0; e->gclock = 0; memset(e->gslots, 0, sizeof e->gslots);
     if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail(-3, "srtCreate: no current HIP device"); }
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
@@ -184,11 +207,14 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
         EALLOC(e->wpack_down[i], S * e->wpack_down_stem[i]);
         EALLOC(e->wpack_up[i], S * e->wpack_up_stem[i]);
     }
+    // fp16 activation storage: every layer between down1 and up6 must run on the fp16-MFMA kernels, which stage aligned
+    // 4-pixel row segments at every level (up1's input is F/64 wide): F % 256 == 0.  Other geometries keep fp32 tensors.
+    e->act16 = cfg->precision == SRT_PREC_F16 && cfg->impl == SRT_IMPL_MFMA && cfg->F % 256 == 0;
     for (int i = 0; i < 6; ++i) {
         e->raw_tile[i] = (size_t)ENC_CH[i][1] * (HW >> (2 * (i + 1)));
-        EALLOC(e->raw[i], S * NT * e->raw_tile[i]);
+        EALLOC(e->raw[i], (S * NT * e->raw_tile[i] + (e->act16 ? 1 : 0)) / (e->act16 ? 2 : 1));
         e->up_tile[i] = (size_t)DEC_CH[i][1] * (HW >> (2 * (5 - i)));
-        EALLOC(e->up[i], S * NT * e->up_tile[i]);
+        EALLOC(e->up[i], (S * NT * e->up_tile[i] + (e->act16 && i < 5 ? 1 : 0)) / (e->act16 && i < 5 ? 2 : 1));      // up6's output (the head's input) stays fp32
     }
     e->rows_cap = NT * cfg->T;
     EALLOC(e->preWin, SRT_FFT); EALLOC(e->postWin, SRT_FFT); EALLOC(e->twiddle, 2 * SRT_FFT);
@@ -272,6 +298,48 @@ int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 }
 
 
+// Small batches (the real-time plugin: 1 tile x 4 stems; BASELINE configs[1]: 1 x 2) leave most CUs idle in the deep layers:
+// the launchers get a workspace so they can cut those layers' K loops into slices (srt_nn2.hip, split-K).
+static void ensure_ws(srt_engine* e, size_t instances)
+{
+    if (e->ws || instances > 16 || e->cfg.impl != SRT_IMPL_MFMA || e->cfg.precision != SRT_PREC_F32) return;
+    const size_t want = (size_t)16 << 20;                  // 64 MiB: 8 slices of the largest split layer at 8 instances
+    if (hipMalloc((void**)&e->ws, want * sizeof(float)) == hipSuccess) e->ws_floats = want;
+    else { e->ws = nullptr; (void)hipGetLastError(); }
+}
+
+// Run `issue` (a function that only enqueues work on e->stream) through the graph cache when graph mode is on.
+template <class F>
+static int run_graphed(srt_engine* e, const GraphKey& key, F&& issue)
+{
+    if (!e->graph_mode || e->timing || !e->stream) return issue();      // the legacy null stream cannot be captured
+    for (GraphSlot& g : e->gslots)
+        if (g.exec && !memcmp(&g.key, &key, sizeof key)) {
+            g.used = ++e->gclock;
+            HIPCHK(hipGraphLaunch(g.exec, e->stream));
+            return 0;
+        }
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e->graph_mode = 0; return issue(); }
+    const int rc = issue();
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t er = hipStreamEndCapture(e->stream, &graph);
+    if (rc == 0 && er == hipSuccess && graph) er = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (rc || er != hipSuccess || !exec) {                               // capture is not available here: fall back to plain launches for good
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        e->graph_mode = 0;
+        return rc ? rc : issue();
+    }
+    GraphSlot* v = &e->gslots[0];
+    for (GraphSlot& g : e->gslots) if (!g.exec || g.used < v->used) { v = &g; if (!g.exec) break; }
+    if (v->exec) hipGraphExecDestroy(v->exec);
+    if (v->graph) hipGraphDestroy(v->graph);
+    v->key = key; v->graph = graph; v->exec = exec; v->used = ++e->gclock;
+    HIPCHK(hipGraphLaunch(exec, e->stream));
+    return 0;
+}
+
 // Sub-networks [s0, s0+ns) on ntiles tiles.  Buffers keep their all-stem layout (stem stride = ntiles instances), so a
 // later call for other stems of the same batch lands beside this one's results.
 static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int s0, int ns)
@@ -284,13 +352,9 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     for (int s = s0; s < s0 + ns; ++s) if (!e->have_coeff[s]) return fail(-5, "srtForward: weights not set for every stem");
     const size_t HW = (size_t)T * F;
     e->last_ntiles = ntiles;
-    // Small batches (the real-time plugin: 1 tile x 4 stems; BASELINE configs[1]: 1 x 2) leave most CUs idle in the deep layers:
-    // give the launchers a workspace so they can cut those layers' K loops into slices (srt_nn2.hip, split-K).
-    if (!e->ws && (size_t)ns * ntiles <= 16 && e->cfg.impl == SRT_IMPL_MFMA && e->cfg.precision == SRT_PREC_F32) {
-        const size_t want = (size_t)16 << 20;              // 64 MiB: 8 slices of the largest split layer at 8 instances
-        if (hipMalloc((void**)&e->ws, want * sizeof(float)) == hipSuccess) e->ws_floats = want;
-        else { e->ws = nullptr; (void)hipGetLastError(); }
-    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (e->stream) (void)hipStreamIsCapturing(e->stream, &cap);
+    if (cap == hipStreamCaptureStatusNone) ensure_ws(e, (size_t)ns * ntiles);      // (no allocation inside a capture: callers pre-allocate)
     const bool small = e->ws && (size_t)ns * ntiles <= 16;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
@@ -307,15 +371,17 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             else {
                 // the previous layer's conv + bias; its batch-norm + activation (spleeter.c:188) is applied by this layer while staging
                 const LayerOff& P = e->lo.down[i - 1];
-                p.srcA = e->raw[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1]; p.srcA_stem = (size_t)ntiles * e->raw_tile[i - 1]; p.srcA_tile = e->raw_tile[i - 1];
+                p.srcA = eoff(e, e->raw[i - 1], (size_t)s0 * ntiles * e->raw_tile[i - 1]); p.srcA_stem = (size_t)ntiles * e->raw_tile[i - 1]; p.srcA_tile = e->raw_tile[i - 1];
                 p.inShift = cbase + P.bn; p.inScale = cbase + P.bn + P.cout;
+                p.in16 = e->act16;
             }
             p.srcB = p.srcA;
             p.wraw = cbase + L.w; p.bias = cbase + L.b;
             p.coeff_stem = SRT_COEFF_STRIDE;
             p.wpack = e->wpack_down[i] + (size_t)s0 * e->wpack_down_stem[i]; p.wpack_stem = e->wpack_down_stem[i];
             p.CP = L.cp;
-            p.outRaw = e->raw[i] + (size_t)s0 * ntiles * e->raw_tile[i];
+            p.outRaw = eoff(e, e->raw[i], (size_t)s0 * ntiles * e->raw_tile[i]);
+            p.out16 = e->act16;
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
@@ -331,6 +397,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
                 rc2 = srt_launch_enc_f16(p, e->stream);
             }
+            if (e->act16 && i > 0 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for an encoder layer");
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_enc2(p, e->stream);
             if (rc2 < 0) return fail(-2, "encoder launch failed");
             if (rc2 == 1 && srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
@@ -340,18 +407,19 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             SrtConvParams p; memset(&p, 0, sizeof p);
             p.Cin = L.cin; p.Cout = L.cout; p.H = T >> (6 - i); p.W = F >> (6 - i); p.ntiles = ntiles; p.nstems = ns;
             const int sk = 5 - i;                                               // skip tensor = raw[5-i]; up1 consumes conv6 alone
-            p.srcA = e->raw[sk] + (size_t)s0 * ntiles * e->raw_tile[sk]; p.srcA_stem = (size_t)ntiles * e->raw_tile[sk]; p.srcA_tile = e->raw_tile[sk];
+            p.srcA = eoff(e, e->raw[sk], (size_t)s0 * ntiles * e->raw_tile[sk]); p.srcA_stem = (size_t)ntiles * e->raw_tile[sk]; p.srcA_tile = e->raw_tile[sk];
             if (i == 0) { p.CA = L.cin; p.srcB = p.srcA; }
             else {
                 p.CA = L.cin / 2;
-                p.srcB = e->up[i - 1] + (size_t)s0 * ntiles * e->up_tile[i - 1]; p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];
+                p.srcB = eoff(e, e->up[i - 1], (size_t)s0 * ntiles * e->up_tile[i - 1]); p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];
             }
+            p.in16 = e->act16; p.out16 = e->act16 && i < 5;
             p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
             p.coeff_stem = SRT_COEFF_STRIDE;
             p.wpack = e->wpack_up[i] + (size_t)s0 * e->wpack_up_stem[i]; p.wpack_stem = e->wpack_up_stem[i];
             p.CP = L.cp;
             p.outRaw = nullptr;
-            p.outAct = e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
+            p.outAct = i < 5 ? eoff(e, e->up[i], (size_t)s0 * ntiles * e->up_tile[i]) : e->up[i] + (size_t)s0 * ntiles * e->up_tile[i];
             p.out_stem = (size_t)ntiles * e->up_tile[i]; p.out_tile = e->up_tile[i];
             p.act = actD; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
@@ -364,6 +432,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
                 rc2 = srt_launch_dec_f16(p, e->stream);
             }
+            if (e->act16 && i < 5 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for a decoder layer");
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_dec2(p, e->stream);
             if (rc2 < 0) return fail(-2, "decoder launch failed");
             if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
@@ -385,7 +454,14 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
 int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
 {
     if (!e) return fail(-1, "srtForward: null argument");
-    return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems);
+    if (!e->graph_mode) return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems);
+    DeviceScope ds(e->device);
+    if (ntiles >= 1) ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
+    GraphKey k; memset(&k, 0, sizeof k);
+    k.kind = 1; k.p0 = d_mag; k.p2 = d_masks; k.ntiles = ntiles; k.ns = e->cfg.n_stems;
+    const int rc = run_graphed(e, k, [&]() { return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems); });
+    if (!rc) e->last_ntiles = ntiles;
+    return rc;
 }
 
 int srtForwardStems(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int stem0, int nstems)
@@ -453,18 +529,41 @@ int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_mas
     return 0;
 }
 
+static int separate_issue(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_out)
+{
+    const int T = e->cfg.T;
+    const size_t ntiles = (rows + T - 1) / T;
+    int rc = srtStftEx(e, d_L, d_R, n, frames, rows, (float*)e->spec, e->mag);
+    if (rc) return rc;
+    rc = forward_range(e, e->mag, (int)ntiles, e->masks, 0, e->cfg.n_stems);
+    if (rc) return rc;
+    if (e->cfg.ratio_mask && (rc = srtRatioMask(e, e->masks, (int)ntiles))) return rc;
+    return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+}
+
 int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_out)
 {
     if (!e) return fail(-1, "srtSeparate: null engine");
     const int T = e->cfg.T;
     const size_t ntiles = (rows + T - 1) / T;
-    if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparate: signal longer than max_tiles * T frames");
-    int rc = srtStftEx(e, d_L, d_R, n, frames, rows, (float*)e->spec, e->mag);
-    if (rc) return rc;
-    rc = srtForward(e, e->mag, (int)ntiles, e->masks);
-    if (rc) return rc;
-    if (e->cfg.ratio_mask && (rc = srtRatioMask(e, e->masks, (int)ntiles))) return rc;
-    return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+    if (rows < 1 || ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparate: signal longer than max_tiles * T frames");
+    if (!e->graph_mode) return separate_issue(e, d_L, d_R, n, frames, rows, d_out);
+    DeviceScope ds(e->device);
+    ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
+    GraphKey k; memset(&k, 0, sizeof k);
+    k.kind = 2; k.p0 = d_L; k.p1 = d_R; k.p2 = d_out; k.n = n; k.frames = frames; k.rows = rows;
+    const int rc = run_graphed(e, k, [&]() { return separate_issue(e, d_L, d_R, n, frames, rows, d_out); });
+    if (!rc) e->last_ntiles = (int)ntiles;
+    return rc;
+}
+
+int srtSetGraphMode(srt_engine* e, int enable)
+{
+    if (!e) return fail(-1, "null engine");
+    DeviceScope ds(e->device);
+    if (!enable) { hipStreamSynchronize(e->stream); free_graphs(e); }
+    e->graph_mode = enable != 0;
+    return 0;
 }
 
 // iSTFT of one spectrum under ONE stem's mask (or none) into a [2][len] destination
@@ -682,14 +781,19 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     else return fail(-1, "srtCopyTensor: unknown tensor %s", name);
     if (per > max_floats) return fail(-1, "srtCopyTensor: destination too small");
     // instance stride = ntiles of the last srtForward call
-    const float* src = base + ((size_t)stem * e->last_ntiles + tile) * per;
+    const bool halves = e->act16 && !(name[0] == 'u' && idx == 5);           // up6 (the head's input) is always fp32
+    const float* src = halves ? eoff(e, const_cast<float*>(base), ((size_t)stem * e->last_ntiles + tile) * per) : base + ((size_t)stem * e->last_ntiles + tile) * per;
     float* tmp = nullptr;
     if (derived) {
         // "actN" is no longer stored: the next encoder layer applies act(bn(convN)) while staging.  Materialise it for the tap.
         const LayerOff& L = e->lo.down[idx];
         const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
         HIPCHK(hipMalloc((void**)&tmp, per * sizeof(float)));
-        if (srt_launch_bn_act(src, tmp, c + L.bn + L.cout, c + L.bn, L.cout, per / L.cout, e->cfg.stem_mode[stem] ? SRT_ACT_ELU : SRT_ACT_LEAKY, e->cfg.variant, e->stream)) { hipFree(tmp); return fail(-2, "bn-act launch failed"); }
+        if (srt_launch_bn_act(src, halves, tmp, c + L.bn + L.cout, c + L.bn, L.cout, per / L.cout, e->cfg.stem_mode[stem] ? SRT_ACT_ELU : SRT_ACT_LEAKY, e->cfg.variant, e->stream)) { hipFree(tmp); return fail(-2, "bn-act launch failed"); }
+        src = tmp;
+    } else if (halves) {
+        HIPCHK(hipMalloc((void**)&tmp, per * sizeof(float)));
+        if (srt_launch_half_to_float(src, tmp, per, e->stream)) { hipFree(tmp); return fail(-2, "conversion launch failed"); }
         src = tmp;
     }
     hipError_t er = hipStreamSynchronize(e->stream);

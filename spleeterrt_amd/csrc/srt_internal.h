@@ -52,6 +52,10 @@ struct SrtConvParams {
     // ws[slice][same offsets as the output tensor] and srt_splitk_reduce adds the slices in slice order (bit-stable run to
     // run) and applies the layer's epilogue.  The launcher picks ksplit; ws_floats = capacity of ws (0: never split).
     float* ws; size_t ws_floats; int ksplit; size_t ws_slice;
+    // fp16 activation storage (srt_config.precision == SRT_PREC_F16): the tensors behind srcA / srcB (in16) and outRaw / outAct
+    // (out16) hold IEEE halves instead of floats - same planar layout, same strides IN ELEMENTS, half the HBM bytes.  The
+    // pointers keep their float type in this struct; kernels that honour the flags reinterpret them.
+    int in16, out16;
     float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
     float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)
     size_t out_stem, out_tile;
@@ -72,7 +76,8 @@ struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sig
 int  srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_head(const SrtHeadParams& p, hipStream_t s);
-int  srt_launch_bn_act(const float* raw, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s);
+int  srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s);
+int  srt_launch_half_to_float(const void* src, float* dst, size_t n, hipStream_t s);
 int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 // v2 kernels (srt_nn2.hip): return 1 when the layer geometry is not covered (caller falls back to the v1 kernels)

@@ -102,17 +102,27 @@ __global__ void srt_dec_naive(const SrtConvParams p)
 
 // act(bn(raw)) of one instance into a scratch tensor: what the next encoder layer applies while staging, materialised only
 // for srtCopyTensor("actN") (debug / parity taps)
-__global__ void srt_bn_act_kernel(const float* __restrict__ raw, float* __restrict__ out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant)
+__global__ void srt_bn_act_kernel(const float* __restrict__ raw, int raw16, float* __restrict__ out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant)
 {
     const size_t total = (size_t)C * hw;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e / hw);
-        out[e] = srt_enc_epilogue(raw[e], scale[c], shift[c], kind, variant);
+        const float v = raw16 ? (float)reinterpret_cast<const _Float16*>(raw)[e] : raw[e];
+        out[e] = srt_enc_epilogue(v, scale[c], shift[c], kind, variant);
     }
 }
-int srt_launch_bn_act(const float* raw, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s)
+int srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, out, scale, shift, C, hw, kind, variant);
+    hipLaunchKernelGGL(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, raw16, out, scale, shift, C, hw, kind, variant);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+__global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (float)src[e];
+}
+int srt_launch_half_to_float(const void* src, float* dst, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(srt_half_to_float_kernel, dim3(1024), dim3(256), 0, s, (const _Float16*)src, dst, n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -562,7 +572,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // of the input tile + 1-pixel halo), the 25 x N result goes to LDS only, and each input pixel's 2x2 output quad then
 // GATHERS its taps from LDS (no scatter, no atomics) with bias -> act -> BN fused.  B operands come straight from
 // global memory (every element feeds exactly one MFMA, so LDS staging would buy nothing).
-template <int TH, int TW, int CIN>
+template <int TH, int TW, int CIN, bool IN16 = false>
 __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
 {
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
@@ -597,7 +607,8 @@ __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
         const size_t off = ok ? (size_t)gy * p.W + gx : 0;
 #pragma unroll
         for (int cp = 0; cp < CIN / 2; ++cp) {
-            const float v = srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
+            const float v = IN16 ? (float)srt_src_channel_t<_Float16>(p, stem, tile, 2 * cp + half, hw)[off]      // fp16 activation storage
+                                 : srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
             b[i][cp] = ok ? v : 0.0f;
         }
     }
@@ -674,6 +685,7 @@ static int launch_naive(void (*k)(const SrtConvParams), const SrtConvParams& p, 
 
 int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
 {
+    if (p.in16 || p.out16) return -1;                     // the fallback kernels only know fp32 tensors (the engine keeps fp32 storage where they may run)
     const int Ho = p.H / 2, Wo = p.W / 2;
     if (impl != 0) return launch_naive(srt_enc_naive, p, (size_t)p.Cout * Ho * Wo, s);
     const int KC2 = 2;
@@ -687,6 +699,7 @@ int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
 
 int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
+    if ((p.in16 || p.out16) && !(impl == 0 && p.Cout == 1 && p.Cin == 32 && !p.out16)) return -1;   // only up6 reads fp16 tensors here
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
 #define UP6_LAUNCH(TH, TW) hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.nstems * p.ntiles), dim3(256), 0, s, p)
@@ -699,7 +712,8 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 3) UP6_LAUNCH(4, 64);
         else if (v == 4) UP6_LAUNCH(4, 128);
 #endif
-        if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
+        if (v == 0 && p.in16) hipLaunchKernelGGL((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+        else if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }

@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pix_ok && m < mlimit) {
                     if (SPLITK) p.ws[(size_t)bc.ks * p.ws_slice + ob[r] + pbase] = acc[mr][nr][r];      // partial sum; bias is added by the reduce
+                    else if (STEMSTACK && p.out16) reinterpret_cast<_Float16*>(p.outRaw)[ob[r] + pbase] = (_Float16)(acc[mr][nr][r] + bi[r]);   // fp16 activation storage (down1 feeds the fp16-MFMA layers)
                     else p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
                 }
             }
@@ -734,13 +735,15 @@ __global__ void __launch_bounds__(256) srt_splitk_reduce(const SrtConvParams p, 
 
 // How many K slices a launch of `base` workgroups over `nchunks` chunks should be cut into: enough to give every CU work,
 // at least two chunks per slice (prologue / epilogue would dominate otherwise), and no more than the workspace holds.
-static int srt_pick_ksplit(const SrtConvParams& p, long base, int nchunks, size_t out_floats)
+static int srt_pick_ksplit(const SrtConvParams& p, long base, int nchunks, size_t out_floats, size_t plane)
 {
-    if (!p.ws || base >= 192 || nchunks < 4 || out_floats % 4) return 1;
+    if (!p.ws || base >= 192 || nchunks < 4 || plane % 4) return 1;        // the reduce handles one float4 of ONE channel plane per thread
     long ks = (256 + base - 1) / base;
     if (ks > nchunks / 2) ks = nchunks / 2;
     while (ks > 1 && (size_t)ks * out_floats > p.ws_floats) --ks;
-    return ks < 1 ? 1 : (int)ks;
+    if (ks <= 1) return 1;
+    const long cps = (nchunks + ks - 1) / ks;               // chunks per slice ...
+    return (int)((nchunks + cps - 1) / cps);                // ... and no empty slice: the last one starts inside the K range
 }
 
 template <int BM, int WM, int SW, int NSX, int NSY, int KC>
@@ -868,16 +871,16 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
         const int Ho = p.H / 2;
         const size_t outf = (size_t)p.nstems * p.out_stem;
         if (p.Cout <= 32) {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 32), p.Cin / 2, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 32), p.Cin / 2, outf, (size_t)Ho * Wo);
             if (ks > 1) return launch_enc2_splitk<32, 1, 32, 2, 4, 2>(p, ks, s);
         } else if (Wo >= 64) {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 64), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 64, 64), p.Cin / 4, outf, (size_t)Ho * Wo);
             if (ks > 1) return launch_enc2_splitk<64, 2, 32, 2, 4, 4>(p, ks, s);
         } else if (Wo >= 32) {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 8, 32, 64), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 8, 32, 64), p.Cin / 4, outf, (size_t)Ho * Wo);
             if (ks > 1) return launch_enc2_splitk<64, 2, 32, 1, 8, 4>(p, ks, s);
         } else {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 16, 64), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, Ho, Wo, 4, 16, 64), p.Cin / 4, outf, (size_t)Ho * Wo);
             if (ks > 1) return launch_enc2_splitk<64, 2, 16, 1, 2, 4>(p, ks, s);
         }
     }
@@ -938,13 +941,13 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
     {                                                                                    // small batches: split-K (see srt_launch_enc2)
         const size_t outf = (size_t)p.nstems * p.out_stem;
         if (p.Cout <= 32) {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 64, 32), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 64, 32), p.Cin / 4, outf, (size_t)4 * p.H * p.W);
             if (ks > 1) return launch_dec2_splitk<32, 1, 32, 2, 4, 4>(p, ks, s);
         } else if (p.W >= 32) {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 32, 64), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 32, 64), p.Cin / 4, outf, (size_t)4 * p.H * p.W);
             if (ks > 1) return launch_dec2_splitk<64, 2, 32, 1, 4, 4>(p, ks, s);
         } else {
-            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 16, 64), p.Cin / 4, outf);
+            const int ks = srt_pick_ksplit(p, srt_base_wgs(p, p.H, p.W, 4, 16, 64), p.Cin / 4, outf, (size_t)4 * p.H * p.W);
             if (ks > 1) return launch_dec2_splitk<64, 2, 16, 1, 2, 4>(p, ks, s);
         }
     }

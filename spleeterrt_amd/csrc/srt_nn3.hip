@@ -14,6 +14,11 @@
 #include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// A16 (template flag of both kernels): the activation tensors in HBM are fp16 (SrtConvParams::in16 / out16) - the loads bring
+// 4 pixels x 8 B per channel instead of 16 B, the decoder stages them without any conversion, and the epilogues store halves.
+// Only with NSPLIT == 1: the split form exists to keep fp32 accuracy, which fp16 storage would throw away.
 
 // ------------------------------------------------------------------------------------------- packing
 __global__ void srt_pack16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int CP, int dec)
@@ -57,9 +62,10 @@ __device__ __forceinline__ void srt_split(float x, _Float16& hi, _Float16& lo)
 }
 
 // ------------------------------------------------------------------------------------------- decoder, fp16 MFMA
-template <int SW, int NSX, int NSY, int NI, int NSPLIT>
+template <int SW, int NSX, int NSY, int NI, int NSPLIT, bool A16 = false>
 __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
 {
+    static_assert(!A16 || NSPLIT == 1, "fp16 storage only with rounded activations");
     constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
     static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
     constexpr int PH = TH + 2, PC = TW + 8, RW4 = PC / 4;
@@ -81,7 +87,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;          // halves per 16-channel group
 
-    float4 pin[NLD][8];
+    float4 pin[A16 ? 1 : NLD][8];
+    h4 pinh[A16 ? NLD : 1][8];
     auto load_patch = [&](int cg) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -89,11 +96,21 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
             const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
             const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * j, tile = tile0 + il;
             const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+            if (A16) {
+                const _Float16* src = srt_src_channel_t<_Float16>(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
-                pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 8; ++q) {
+                    const h4 v = *reinterpret_cast<const h4*>(src + (size_t)q * hw);
+                    const h4 z = { (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f };
+                    pinh[i][q] = ok ? v : z;
+                }
+            } else {
+                const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
+                    pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     };
@@ -107,7 +124,12 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
                 h8 hi[4], lo[4];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float x[4] = { pin[i][q].x, pin[i][q].y, pin[i][q].z, pin[i][q].w };
+                    if (A16) {                            // already halves: a register transpose (channel-major -> pixel-major), no arithmetic
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) hi[px][q] = pinh[i][q][px];
+                        continue;
+                    }
+                    const float x[4] = { pin[A16 ? 0 : i][q].x, pin[A16 ? 0 : i][q].y, pin[A16 ? 0 : i][q].z, pin[A16 ? 0 : i][q].w };
 #pragma unroll
                     for (int px = 0; px < 4; ++px) {
                         _Float16 a, b;
@@ -209,7 +231,10 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
                     float2 v;
                     v.x = srt_dec_epilogue(acc[py * 2 + 0][nr][r], bi[r], sc[r], sf[r], actp);
                     v.y = srt_dec_epilogue(acc[py * 2 + 1][nr][r], bi[r], sc[r], sf[r], actp);
-                    *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
+                    if (A16) {
+                        const h2 hv = { (_Float16)v.x, (_Float16)v.y };
+                        *reinterpret_cast<h2*>(reinterpret_cast<_Float16*>(p.outAct) + obase + (size_t)m * ohw + (size_t)py * Wo) = hv;
+                    } else *reinterpret_cast<float2*>(p.outAct + obase + (size_t)m * ohw + (size_t)py * Wo) = v;
                 }
             }
         }
@@ -221,9 +246,10 @@ template <int TW, int SW> struct Enc16Pad {
     static constexpr int base = TW + 4;
     static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
 };
-template <int SW, int NSX, int NSY, int NI, int NSPLIT>
+template <int SW, int NSX, int NSY, int NI, int NSPLIT, bool A16 = false>
 __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 {
+    static_assert(!A16 || NSPLIT == 1, "fp16 storage only with rounded activations");
     constexpr int BM = 32, SH = 32 / SW, TW = NSX * SW, TH = NSY * SH, NS = NSX * NSY * NI, NR = NS / 4;
     static_assert(SH * SW == 32 && NR * 4 == NS, "bad tile");
     constexpr int PH = 2 * TH + 3, RW4 = (2 * TW + 8) / 4, PWH = Enc16Pad<TW, SW>::value;
@@ -251,7 +277,8 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;
 
-    float4 pin[NLD][8];
+    float4 pin[A16 ? 1 : NLD][8];
+    h4 pinh[A16 ? NLD : 1][8];
     auto load_patch = [&](int cg) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -259,11 +286,21 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
             const int j = e % RW4, ru = e / RW4, r = ru % PH, il = (ru / PH) % NI, gg = ru / (PH * NI);
             const int gy = 2 * ty0 + r - 1, gx = 2 * tx0 - 4 + 4 * j, tile = tile0 + il;
             const bool ok = tile < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-            const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+            if (A16) {
+                const _Float16* src = srt_src_channel_t<_Float16>(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
-                pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 8; ++q) {
+                    const h4 v = *reinterpret_cast<const h4*>(src + (size_t)q * hw);
+                    const h4 z = { (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f };
+                    pinh[i][q] = ok ? v : z;
+                }
+            } else {
+                const float* src = srt_src_channel(p, stem, ok ? tile : tile0, cg * 16 + gg * 8, hw) + (ok ? (size_t)gy * p.W + gx : 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)q * hw);
+                    pin[i][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     };
@@ -282,7 +319,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
                 h8 hi[4], lo[4];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float4 pv = pin[i][q];
+                    float4 pv;
+                    if (A16) pv = make_float4((float)pinh[i][q][0], (float)pinh[i][q][1], (float)pinh[i][q][2], (float)pinh[i][q][3]);
+                    else pv = pin[A16 ? 0 : i][q];
                     if (xform) {
                         const int c = cg * 16 + gg * 8 + q;
                         const float sc = s_ibn[c], sf = s_ibn[SRT_ENC_MAX_CIN + c];
@@ -372,7 +411,10 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (pix_ok && m < p.Cout) p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];      // conv + bias, stored once
+            if (pix_ok && m < p.Cout) {                                                            // conv + bias, stored once
+                if (A16) reinterpret_cast<_Float16*>(p.outRaw)[obase + (size_t)m * ohw] = (_Float16)(acc[nr][r] + bi[r]);
+                else p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];
+            }
         }
     }
 }
@@ -384,6 +426,7 @@ static int launch_dec16(const SrtConvParams& p, hipStream_t s)
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
     if (p.nsplit == 2) hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else if (p.in16) hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -394,6 +437,7 @@ static int launch_enc16(const SrtConvParams& p, hipStream_t s)
     const int Ho = p.H / 2, Wo = p.W / 2;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
     if (p.nsplit == 2) hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else if (p.in16) hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -401,6 +445,7 @@ static int launch_enc16(const SrtConvParams& p, hipStream_t s)
 int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
 {
     if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 32) return 1;       // down1 (Cin = 2) stays on the fp32 kernel
+    if (p.in16 != p.out16 || (p.in16 && p.nsplit == 2)) return -1;           // fp16 storage: both sides, rounded form only
     const int Wo = p.W / 2;
     int v = p.nsplit == 2 ? 1 : 0;                               // the split variant doubles the patch planes: bigger tiles measured faster there
 #ifdef SRT_TUNING
@@ -420,6 +465,7 @@ int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
 int srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s)
 {
     if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 16 || p.CA % 16) return 1;   // up6 (Cout = 1) stays fp32
+    if (p.in16 != p.out16 || (p.in16 && p.nsplit == 2)) return -1;
     if (p.W >= 64) return launch_dec16<32, 2, 4, 1>(p, s);                   // 4 rows x 64 cols
     if (p.W >= 32) return launch_dec16<32, 1, 8, 1>(p, s);                   // 8 rows x 32 cols (whole 8x32 instance for up2)
     return launch_dec16<16, 1, 2, 4>(p, s);                                  // up1: 4 instances of 4x16

@@ -132,6 +132,7 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         if (srtCreate(&cfg, s->nn, &s->eng)) { s->eng = nullptr; stream_fail("Spleeter4StemsInit", nullptr); return; }
         for (int k = 0; k < 4; ++k)
             if (srtSetCoeffHost(s->eng, k, coeffProvider[k])) { stream_fail("Spleeter4StemsInit(weights)", nullptr); return; }
+        srtSetGraphMode(s->eng, 1);                           // the four U-Nets run on the same buffers every T hops: replay one hipGraph per mask buffer
         const size_t specF = 2 * 2 * (size_t)T * SRT_SPEC_LD * 2;
         INITTRY(hipMalloc((void**)&s->d_ring, sizeof s->ring));
         INITTRY(hipMalloc((void**)&s->d_spec, specF * sizeof(float)));

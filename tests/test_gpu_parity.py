@@ -182,7 +182,8 @@ def test_chunked_stream_equals_single_batch(oracle, coeffs):
             parts += stream.separate_stream(small, Ld, Rd, rank, world)
         got = stream.stitch(parts, n, 2)
         assert got.shape == ref.shape
-        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), "world %d" % world
+        # OLA order at the seams + (small batches only) the split-K association of the conv sums
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), "world %d" % world
     big.close(); small.close()
 
 
@@ -203,7 +204,7 @@ def test_host_stream_pipeline_equals_single_batch(oracle, coeffs, max_tiles):
     ref = big.separate(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
     got = eng.separate_host_stream(L, R)
     assert got.shape == ref.shape
-    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()     # OLA order at chunk seams + split-K association at these tiny batches
     again = eng.separate_host_stream(L, R)                   # reusable, deterministic
     assert np.array_equal(got, again)
     big.close(); eng.close()
@@ -391,10 +392,48 @@ def test_forward_stem_range_equals_full(oracle, coeffs):
     part = torch.zeros_like(full)
     eng.forward_stems(x, part, 1, 1)
     eng.forward_stems(x, part, 0, 1)
-    assert torch.equal(full, part)
+    # same arithmetic, but at these tiny batches the deep layers are split-K launches whose slice count follows the number of
+    # instances in the launch: only the association of the K sums may differ
+    assert float((full - part).abs().max()) <= 1e-4
+    again = torch.zeros_like(full)
+    eng.forward_stems(x, again, 1, 1)
+    eng.forward_stems(x, again, 0, 1)
+    assert torch.equal(part, again)                          # run to run: bit-stable (fixed reduction order)
     with pytest.raises(srt.EngineError):
         eng.forward_stems(x, part, 1, 2)
     eng.close()
+
+
+def test_small_batch_split_k_and_graph_replay(oracle, coeffs):
+    """The real-time regime (1 tile x 4 stems at the plugin's 256 x 1536, VST/Source/PluginProcessor.cpp:124): the deep layers run as
+    split-K launches and the whole forward can be replayed as a hipGraph.  Masks vs the CPU oracle, bit-stable run to run,
+    graph replay == eager."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S = 256, 1536, 4
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng = _engine(F=F, T=T, stem_modes=(1,) * S, variant=srt.VARIANT_VST, max_tiles=1)
+        for s in range(S):
+            eng.set_coeff(s, coeffs(s))
+        x = _mag_input(oracle, 1, T, F, seed=31)
+        xd = torch.from_numpy(x).cuda()
+        m1 = eng.forward(xd).clone()
+        m2 = eng.forward(xd).clone()
+        assert torch.equal(m1, m2)
+        eng.set_graph_mode(True)
+        out = torch.empty_like(m1)
+        eng.forward(xd, out)                                 # captures
+        first = out.clone()
+        out.zero_()
+        eng.forward(xd, out)                                 # replays
+        side.synchronize()
+        assert torch.equal(first, m1) and torch.equal(out, m1)
+        eng.set_graph_mode(False)
+        eng.close()
+    for s in (0, 3):
+        y = oracle.forward(coeffs(s), x[0], 1, oracle.VARIANT_VST)
+        assert np.abs(m1[s, 0].cpu().numpy() - y).max() <= MASK_TOL_EXACT
 
 
 def test_ratio_mask(oracle, coeffs):
@@ -453,9 +492,11 @@ def test_full_size_batch_properties(oracle, coeffs):
     assert torch.equal(mag[5], mag[40])
     for j in (6, 31, 62):
         assert torch.equal(masks[:, 5], masks[:, j]), "tile %d differs from tile 5" % j
-    # a tile evaluated alone (batch of 1, slot 0) == the same tile inside the 64-tile batch
+    # a tile evaluated alone (batch of 1, slot 0) == the same tile inside the 64-tile batch; alone, its deep layers run as
+    # split-K launches (small-batch path), so only the association of the K sums differs
     alone = eng.forward(mag[17:18].contiguous())
-    assert torch.equal(alone[:, 0], masks[:, 17])
+    assert float((alone[:, 0] - masks[:, 17]).abs().max()) <= 1e-4
+    assert torch.equal(alone, eng.forward(mag[17:18].contiguous()))      # bit-stable run to run
     # one (tile, stem) against the CPU oracle at the full tile size
     ref = oracle.forward(coeffs(2), mag[5].cpu().numpy(), 1, oracle.VARIANT_VST)
     assert np.abs(masks[2, 5].cpu().numpy() - ref).max() <= MASK_TOL_EXACT
