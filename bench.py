@@ -40,8 +40,8 @@ assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
 # kernel symbol (as rocprofv3 prints it) that runs each layer at T=256, F=1024; layers sharing a symbol have equal FLOPs
 LAYER_SYMBOL = {
     "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 2, false, 0, false>",
-    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false>", "down4": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false>",
-    "down5": "srt_enc_mfma2<64, 2, 32, 1, 8, 1, 4, false, 0, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false>",
+    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false>", "down4": "srt_enc_mfma2<128, 2, 32, 2, 4, 1, 2, false, 0, false>",
+    "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false>",
     "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false>",
     "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0, false>",
     "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",

@@ -98,6 +98,7 @@ static int write_wav(const char *path, const float *L, const float *R, size_t fr
     PUT32(42, 4); PUT32(46, (uint32_t)frames); PUT32(54, data);
     fwrite(h, 1, sizeof h, f);
     float *il = (float *)malloc((frames ? frames : 1) * 8);
+    if (!il) { fprintf(stderr, "out of host memory writing %s\n", path); fclose(f); return -1; }
     for (size_t i = 0; i < frames; ++i) { il[2 * i] = L[i + FFT]; il[2 * i + 1] = R[i + FFT]; }       /* channel_joinFloat(..., preshift 4096), main.c:806 */
     const size_t w = fwrite(il, 8, frames, f);
     free(il);
@@ -129,14 +130,18 @@ int main(int argc, char **argv)
     const size_t nframes = read_wav(argv[5], &pcm, &channels, &rate);
     if (!nframes) return -1;
     if (rate != 44100) { fprintf(stderr, "%s: %u Hz — only 44.1 kHz input is accepted (the resampler is outside this harness)\n", argv[5], rate); return -1; }
+    /* the outputs are float32 stereo RIFF files: 8 bytes per frame under a 32-bit chunk size (main.c writes the same container) */
+    if ((uint64_t)nframes * 8u + 58u > 0xFFFFFFFFull) { fprintf(stderr, "%s: %zu frames do not fit a float32 stereo RIFF/WAVE output (4 GiB limit); split the input\n", argv[5], nframes); return -1; }
     const size_t readcount = (nframes + FFT - 1) / FFT, finalSize = FFT * readcount + 2 * FFT;
     float *inL = (float *)calloc(finalSize, sizeof(float)), *inR = (float *)calloc(finalSize, sizeof(float));
+    if (!inL || !inR) { fprintf(stderr, "out of host memory (%zu samples per channel)\n", finalSize); return -1; }
     for (size_t i = 0; i < nframes; ++i) { inL[FFT + i] = pcm[i * channels]; inR[FFT + i] = pcm[i * channels + (channels - 1)]; }
     free(pcm);
 
     const size_t nhalf = srtCoeffBytes() / 4;
     uint16_t *halfs = (uint16_t *)malloc(2 * nhalf * sizeof(uint16_t));
     FILE *wf = fopen(wpath, "rb");
+    if (!halfs) { fprintf(stderr, "out of host memory\n"); return -1; }
     if (!wf || fread(halfs, sizeof(uint16_t), 2 * nhalf, wf) != 2 * nhalf) { fprintf(stderr, "cannot read %zu halves from %s\n", 2 * nhalf, wpath); return -1; }
     fclose(wf);
     printf("Audio & model file loading takes: %1.14lf sec\n", now() - t0);
@@ -151,7 +156,10 @@ int main(int argc, char **argv)
     if (srtCreate(&cfg, 0, &e)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
     if (srtSetCoeffFp16Host(e, 0, halfs) || srtSetCoeffFp16Host(e, 1, halfs + nhalf)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
     free(halfs);
+    /* The whole file is one resident batch (every tile of both sub-networks lives in HBM at once: ~0.1 GB per tile at 512 x 1024,
+     * i.e. about an hour of audio per 100 GB); srtCreate reports a clean error when the file is too long for the device. */
     float *out = (float *)malloc((size_t)stems * 2 * len * sizeof(float));
+    if (!out) { fprintf(stderr, "out of host memory (%zu output samples)\n", (size_t)stems * 2 * len); return -1; }
     t0 = now();
     if (srtSeparateCliHost(e, inL, inR, finalSize, stems, out)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
     printf("Inference neural networks on the GPU takes %1.14lf sec (%d tiles of %zu x %zu, %d outputs)\n", now() - t0, cfg.max_tiles, T, F, stems);

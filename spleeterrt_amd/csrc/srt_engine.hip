@@ -91,7 +91,8 @@ struct srt_engine {
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
-    size_t raw_tile[6], up_tile[6];                    // floats per instance
+    size_t raw_tile[6], up_tile[6];                    // elements per instance
+    float* act16buf[5];                                // fp16-storage mode only: act(bn(raw_i)) as halves, written by the producer
     bool act16;                                        // raw[0..5] and up[0..4] hold IEEE halves (precision F16 on a supported geometry)
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
@@ -161,7 +162,7 @@ static void free_all(srt_engine* e)
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
-    for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); }
+    for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act16buf[i]) hipFree(e->act16buf[i]); }
     void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->spec2, e->mag, e->masks, e->frames };
     for (void* m : misc) if (m) hipFree(m);
     for (auto& t : e->tlog) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -183,7 +184,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
-    memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up);
+    memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
     e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->spec2 = nullptr; e->mag = e->masks = e->frames = nullptr;
     e->cfg = *cfg; e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
     if (e->lo.total != SRT_COEFF_FLOATS) { delete e; return fail(-4, "internal: weight layout size mismatch"); }
@@ -213,6 +214,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     for (int i = 0; i < 6; ++i) {
         e->raw_tile[i] = (size_t)ENC_CH[i][1] * (HW >> (2 * (i + 1)));
         EALLOC(e->raw[i], (S * NT * e->raw_tile[i] + (e->act16 ? 1 : 0)) / (e->act16 ? 2 : 1));
+        if (e->act16 && i < 5) EALLOC(e->act16buf[i], (S * NT * e->raw_tile[i] + 1) / 2);
         e->up_tile[i] = (size_t)DEC_CH[i][1] * (HW >> (2 * (5 - i)));
         EALLOC(e->up[i], (S * NT * e->up_tile[i] + (e->act16 && i < 5 ? 1 : 0)) / (e->act16 && i < 5 ? 2 : 1));      // up6's output (the head's input) stays fp32
     }
@@ -371,9 +373,14 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             else {
                 // the previous layer's conv + bias; its batch-norm + activation (spleeter.c:188) is applied by this layer while staging
                 const LayerOff& P = e->lo.down[i - 1];
-                p.srcA = eoff(e, e->raw[i - 1], (size_t)s0 * ntiles * e->raw_tile[i - 1]); p.srcA_stem = (size_t)ntiles * e->raw_tile[i - 1]; p.srcA_tile = e->raw_tile[i - 1];
-                p.inShift = cbase + P.bn; p.inScale = cbase + P.bn + P.cout;
-                p.in16 = e->act16;
+                p.srcA_stem = (size_t)ntiles * e->raw_tile[i - 1]; p.srcA_tile = e->raw_tile[i - 1];
+                if (e->act16) {            // fp16 storage: the producer wrote act(bn(raw)) as a second fp16 tensor (see srt_enc_f16)
+                    p.srcA = eoff(e, e->act16buf[i - 1], (size_t)s0 * ntiles * e->raw_tile[i - 1]);
+                    p.in16 = 1;
+                } else {
+                    p.srcA = e->raw[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1];
+                    p.inShift = cbase + P.bn; p.inScale = cbase + P.bn + P.cout;
+                }
             }
             p.srcB = p.srcA;
             p.wraw = cbase + L.w; p.bias = cbase + L.b;
@@ -382,6 +389,10 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.CP = L.cp;
             p.outRaw = eoff(e, e->raw[i], (size_t)s0 * ntiles * e->raw_tile[i]);
             p.out16 = e->act16;
+            if (e->act16 && i < 5) {
+                p.outAct = eoff(e, e->act16buf[i], (size_t)s0 * ntiles * e->raw_tile[i]);
+                p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
+            }
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }

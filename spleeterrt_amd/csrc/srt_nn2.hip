@@ -133,9 +133,14 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // waitcnt pass then puts an s_waitcnt vmcnt(0) in front of the first ds_read that follows a global_load_lds into the same
     // object - i.e. at the TOP of the MFMA block, so the weight DMA and the patch prefetch of chunk ch+1 were waited for before
     // the MFMAs of chunk ch instead of running under them (this was the "fixed cost" of every encoder layer: 10-15 %).
-    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + BM + 2 * SRT_ENC_MAX_CIN];
-    float* s_epi = s_mem + KC * CHS + 2 * WSLAB;        // bias of this workgroup's BM rows (see the epilogue)
-    float* s_ibn = s_epi + BM;                          // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
+    // (every byte counts: down6's tile is 81 664 B, and two workgroups per CU must fit in 163 840 B)
+    constexpr int NEPI = STEMSTACK ? 3 * BM : BM, NIBN = STEMSTACK ? 0 : 2 * SRT_ENC_MAX_CIN;
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + NEPI + NIBN];
+#ifndef SRT_TUNING
+    static_assert(sizeof(s_mem) * 2 <= 160 * 1024, "two workgroups per CU");       // every shipped tile shape; the measurement build has larger ones
+#endif
+    float* s_epi = s_mem + KC * CHS + 2 * WSLAB;        // bias (| BN scale | BN shift: down1 in fp16-storage mode) of this workgroup's BM rows
+    float* s_ibn = s_epi + NEPI;                        // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
 
@@ -265,10 +270,18 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // counted s_waitcnt vmcnt(n) in front of every output element, and since stores count in vmcnt too each of those waits also
     // drained the stores issued so far: the epilogue ran at one store round trip per element (0.36 ms of down2's 1.08 ms).
     const int mlimit = STEMSTACK ? p.stack * p.Cout : p.Cout;
+    // fp16 activation storage (down1 only, the fp32 layer in front of the fp16-MFMA encoders): raw AND act(bn(raw)) leave as
+    // halves, the second one for down2 (see srt_enc_f16: there the consumer-side transform would cost more than the MFMAs)
+    const bool twoOut = STEMSTACK && p.out16 && p.outAct != nullptr && p.bnScale != nullptr;
     if (tid < BM) {
         const int m = min(m0 + tid, mlimit - 1);
         const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
-        s_epi[tid] = p.bias[st * p.coeff_stem + co];
+        const size_t ci = st * p.coeff_stem + co;
+        s_epi[tid] = p.bias[ci];
+        if (STEMSTACK) {                                   // (only the stacked kernel has these two rows)
+            s_epi[BM + tid] = twoOut ? p.bnScale[ci] : 0.0f;
+            s_epi[2 * BM + tid] = twoOut ? p.bnShift[ci] : 0.0f;
+        }
     }
     if (xform) {
         for (int c = tid; c < p.Cin; c += 256) {
@@ -350,14 +363,20 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     for (int mr = 0; mr < MR; ++mr) {
         float bi[16];
         size_t ob[16];
+        float sc2[16], sf2[16];                        // fp16-storage mode of down1 only: BN constants of the rows, activation of each 16-row stem group
+        int stg[2] = { 0, 0 };
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int m = min(m0 + row, mlimit - 1);
             const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
             bi[r] = s_epi[row];
+            sc2[r] = twoOut ? s_epi[BM + row] : 0.0f; sf2[r] = twoOut ? s_epi[2 * BM + row] : 0.0f;
+            if (STEMSTACK && (r & 7) == 0) stg[r >> 3] = st;            // registers 0..7 are one stem's channels, 8..15 the next stem's (Cout == 16)
             ob[r] = st * p.out_stem + (size_t)co * ohw;
         }
+        const SrtAct apg[2] = { srt_act_params(STEMSTACK && ((p.elu_mask >> stg[0]) & 1u) ? SRT_ACT_ELU : p.act, p.variant),
+                                srt_act_params(STEMSTACK && ((p.elu_mask >> stg[1]) & 1u) ? SRT_ACT_ELU : p.act, p.variant) };
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int s = wn * NR + nr;
@@ -370,7 +389,11 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pix_ok && m < mlimit) {
                     if (SPLITK) p.ws[(size_t)bc.ks * p.ws_slice + ob[r] + pbase] = acc[mr][nr][r];      // partial sum; bias is added by the reduce
-                    else if (STEMSTACK && p.out16) reinterpret_cast<_Float16*>(p.outRaw)[ob[r] + pbase] = (_Float16)(acc[mr][nr][r] + bi[r]);   // fp16 activation storage (down1 feeds the fp16-MFMA layers)
+                    else if (STEMSTACK && p.out16) {                                            // fp16 activation storage (down1 feeds the fp16-MFMA layers)
+                        const float v = acc[mr][nr][r] + bi[r];
+                        reinterpret_cast<_Float16*>(p.outRaw)[ob[r] + pbase] = (_Float16)v;
+                        if (twoOut) reinterpret_cast<_Float16*>(p.outAct)[ob[r] + pbase] = (_Float16)srt_enc_epilogue(v, sc2[r], sf2[r], apg[r >> 3]);
+                    }
                     else p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
                 }
             }
@@ -393,9 +416,11 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     constexpr int NTAP = CLASSSTACK ? 15 : 25, NCLS = CLASSSTACK ? 2 : 4;
     constexpr int WROWS = KC * NTAP, WSLAB = (WROWS * BM + 255) / 256 * 256;
 
-    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB];
+    constexpr bool EPI_LDS = ABL == 20;                  // tuning: bias / BN constants staged in LDS before the K loop (same LDS object)
+    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + (EPI_LDS ? 3 * BM : 0)];
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
+    float* s_epi = s_mem + KC * CHS + 2 * WSLAB;
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -463,6 +488,13 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     }
     const int aoff = half * NTAP * BM + wm * MR * 32 + l31;
 
+    if (EPI_LDS && tid < BM) {
+        int m = m0 + tid;
+        if (CLASSSTACK) m &= 15;
+        m = min(m, p.Cout - 1);
+        const size_t ci = stem * p.coeff_stem + m;
+        s_epi[tid] = p.bias[ci]; s_epi[BM + tid] = p.bnScale[ci]; s_epi[2 * BM + tid] = p.bnShift[ci];
+    }
     const int nchunks_all = p.Cin / KC;                    // split-K: chunks [chA, nchunks) of the K loop (see srt_enc_mfma2)
     const int cps = SPLITK ? (nchunks_all + p.ksplit - 1) / p.ksplit : nchunks_all;
     const int chA = SPLITK ? bc.ks * cps : 0, nchunks = SPLITK ? min(nchunks_all, chA + cps) : nchunks_all;
@@ -519,6 +551,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (EPI_LDS) { const int row = m - m0; bi[r] = s_epi[row]; sc[r] = s_epi[BM + row]; sf[r] = s_epi[2 * BM + row]; continue; }
             if (CLASSSTACK) m &= 15;                                   // rows = px*16 + co
             m = min(m, p.Cout - 1);
             bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
@@ -809,6 +842,12 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * (STK ? 1 : (p.Cout + BM - 1) / BM) * p.nstems * ((p.ntiles + NI - 1) / NI));
+#ifdef SRT_TUNING
+    if constexpr (!STK) if (tune("decx") == 20) {
+        hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 20>), grid, dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#endif
     hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -897,6 +936,25 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 #endif
         return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, false>(p, s);
     }
+#ifdef SRT_TUNING
+    if (p.Cout >= 128 && tune("bm128")) {                                                // measured alternatives for the 128-channel tiles (see below)
+        const int v = tune("bm128");                                                     // 1: KC = 4 (one workgroup per CU), 2: KC = 2 on every layer, 3: BM = 64 everywhere
+        if (v == 3) {
+            if (Wo >= 64) return launch_enc2_cfg<64, 2, 32, 2, 4, 1, 4, false>(p, s);
+            if (Wo >= 32) return launch_enc2_cfg<64, 2, 32, 1, 8, 1, 4, false>(p, s);
+            return launch_enc2_cfg<64, 2, 16, 1, 2, 4, 4, false>(p, s);
+        }
+        if (Wo >= 64) return v == 1 ? launch_enc2_cfg<128, 2, 32, 2, 4, 1, 4, false>(p, s) : launch_enc2_cfg<128, 2, 32, 2, 4, 1, 2, false>(p, s);
+        if (Wo >= 32) return v == 1 ? launch_enc2_cfg<128, 2, 32, 1, 8, 1, 4, false>(p, s) : launch_enc2_cfg<128, 2, 32, 1, 8, 1, 2, false>(p, s);
+        return v == 1 ? launch_enc2_cfg<128, 2, 16, 1, 2, 4, 4, false>(p, s) : launch_enc2_cfg<128, 2, 16, 1, 2, 4, 2, false>(p, s);
+    }
+#endif
+    // down4 / down5 (Cout >= 128, at least 32 output columns): 128 channels per workgroup with two-channel K-chunks.  The patch and
+    // its BN + activation are staged once per 128 instead of once per 64 output channels, and the smaller chunk keeps two
+    // workgroups per CU (measured: down4 0.881 -> 0.835 ms, down5 0.843 -> 0.813; KC = 4 with one workgroup per CU and the
+    // same shape on down6 are slower).
+    if (p.Cout >= 128 && Wo >= 64) return launch_enc2_cfg<128, 2, 32, 2, 4, 1, 2, false>(p, s);
+    if (p.Cout >= 128 && Wo >= 32) return launch_enc2_cfg<128, 2, 32, 1, 8, 1, 2, false>(p, s);
     if (Wo >= 64) {                                                                      // down3 / down4 class
 #ifdef SRT_TUNING
         switch (tune("eabl")) {                                                          // 1 no loads, 3 constant operands, 4 no patch, 5 no DMA, 8 no scheduling hint

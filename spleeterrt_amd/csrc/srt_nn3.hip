@@ -257,11 +257,11 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
     constexpr int WSLAB = 25 * 512;
     // one LDS object (see srt_enc_mfma2: a second __shared__ array makes the compiler wait for the weight DMA before the MFMAs)
-    constexpr int NCONST = 32 + 2 * SRT_ENC_MAX_CIN;        // floats: bias of the 32 rows | BN scale | BN shift of the input channels
+    constexpr int NCONST = 96 + 2 * SRT_ENC_MAX_CIN;        // floats: bias | BN scale | BN shift of the 32 rows, then BN scale | shift of the input channels
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB + 2 * NCONST];
     static_assert(sizeof(s_mem) <= 160 * 1024 && (NSPLIT * 2 * PLANE + 2 * WSLAB) % 8 == 0, "LDS");
     float* s_epi = reinterpret_cast<float*>(s_mem + NSPLIT * 2 * PLANE + 2 * WSLAB);
-    float* s_ibn = s_epi + 32;
+    float* s_ibn = s_epi + 96;
     _Float16* s_in = s_mem;
     _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
 
@@ -319,9 +319,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
                 h8 hi[4], lo[4];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float4 pv;
-                    if (A16) pv = make_float4((float)pinh[i][q][0], (float)pinh[i][q][1], (float)pinh[i][q][2], (float)pinh[i][q][3]);
-                    else pv = pin[A16 ? 0 : i][q];
+                    if (A16) {                            // fp16 storage: the producer already applied BN + activation; a pure register transpose
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) hi[px][q] = pinh[i][q][px];
+                        continue;
+                    }
+                    float4 pv = pin[A16 ? 0 : i][q];
                     if (xform) {
                         const int c = cg * 16 + gg * 8 + q;
                         const float sc = s_ibn[c], sf = s_ibn[SRT_ENC_MAX_CIN + c];
@@ -360,7 +363,16 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     }
     const int aoff = (g * BM + l31) * 8;
 
-    if (tid < 32) s_epi[tid] = p.bias[stem * p.coeff_stem + min(m0 + tid, p.Cout - 1)];
+    // fp16 storage: the PRODUCER also stores act(bn(v)) as a second fp16 tensor (outAct) for the next encoder layer.  With the
+    // 16x faster fp16 MFMA the consumer-side transform of the fp32 kernels (re-evaluated per halo row and per 32-channel
+    // M block: 44x for down6's input) cost several times the MFMAs themselves; two fp16 stores are the bytes of one fp32 store.
+    const bool twoOut = A16 && p.outAct != nullptr && p.bnScale != nullptr;
+    if (tid < 32) {
+        const size_t ci = stem * p.coeff_stem + min(m0 + tid, p.Cout - 1);
+        s_epi[tid] = p.bias[ci];
+        s_epi[32 + tid] = twoOut ? p.bnScale[ci] : 0.0f;
+        s_epi[64 + tid] = twoOut ? p.bnShift[ci] : 0.0f;
+    }
     if (xform) {
         for (int c = tid; c < p.Cin; c += 256) {
             s_ibn[c] = p.inScale[stem * p.coeff_stem + c];
@@ -398,9 +410,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     }
 
     const size_t ohw = (size_t)Ho * Wo;
-    float bi[16];
+    float bi[16], sc[16], sf[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bi[r] = s_epi[(r & 3) + 8 * (r >> 2) + 4 * g];
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        bi[r] = s_epi[row]; sc[r] = s_epi[32 + row]; sf[r] = s_epi[64 + row];
+    }
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int s = wave * NR + nr;
@@ -411,9 +426,12 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (pix_ok && m < p.Cout) {                                                            // conv + bias, stored once
-                if (A16) reinterpret_cast<_Float16*>(p.outRaw)[obase + (size_t)m * ohw] = (_Float16)(acc[nr][r] + bi[r]);
-                else p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];
+            if (pix_ok && m < p.Cout) {
+                const float v = acc[nr][r] + bi[r];                                               // conv + bias: the skip tensor
+                if (A16) {
+                    reinterpret_cast<_Float16*>(p.outRaw)[obase + (size_t)m * ohw] = (_Float16)v;
+                    if (twoOut) reinterpret_cast<_Float16*>(p.outAct)[obase + (size_t)m * ohw] = (_Float16)srt_enc_epilogue(v, sc[r], sf[r], actp);
+                } else p.outRaw[obase + (size_t)m * ohw] = v;
             }
         }
     }
@@ -445,7 +463,7 @@ static int launch_enc16(const SrtConvParams& p, hipStream_t s)
 int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
 {
     if (!p.wpack16 || p.W % 4 || p.Cin % 16 || p.Cout < 32) return 1;       // down1 (Cin = 2) stays on the fp32 kernel
-    if (p.in16 != p.out16 || (p.in16 && p.nsplit == 2)) return -1;           // fp16 storage: both sides, rounded form only
+    if (p.in16 != p.out16 || (p.in16 && (p.nsplit == 2 || p.inScale))) return -1;   // fp16 storage: both sides, rounded form only, activated input
     const int Wo = p.W / 2;
     int v = p.nsplit == 2 ? 1 : 0;                               // the split variant doubles the patch planes: bigger tiles measured faster there
 #ifdef SRT_TUNING

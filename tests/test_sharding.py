@@ -50,6 +50,29 @@ class OracleEngine:
         return np.stack(outs)
 
 
+    def separate_host_stream(self, L, R, frames=None, rows=None, out=None, pinned=False):
+        """Engine.separate_host_stream stand-in (what stream.separate_host_range / scripts/stream_c4.py call per rank)."""
+        return self.separate_ex(L, R, frames, rows)
+
+
+def test_rank_span_matches_plan():
+    """rank_span (one span per rank, chunked natively by srtSeparateHostStream) covers exactly the chunks plan() lists."""
+    T = 256
+    n = 158769152
+    for world in (1, 2, 8):
+        offs = []
+        for r in range(world):
+            sp = stream.rank_span(n, T, r, world)
+            cs = stream.plan(n, T, 64, r, world)
+            assert sp.tile0 == cs[0].tile0 and sp.tile1 == cs[-1].tile1
+            assert sp.sample0 == cs[0].sample0 and sp.rows == sum(c.rows for c in cs) and sp.frames == sum(c.frames for c in cs)
+            assert sp.sample0 + sp.nsamples == cs[-1].sample0 + cs[-1].nsamples
+            offs.append((sp.out_offset, sp.rows))
+        for (o0, r0), (o1, _) in zip(offs, offs[1:]):
+            assert o0 + r0 * 1024 == o1                                              # consecutive spans meet (+3072 overlap added when stitched)
+        assert offs[-1][0] + offs[-1][1] * 1024 + 3072 == stream.total_output_length(n)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -67,8 +90,10 @@ def _worker(rank, world, port, n, T, F, q):
     L, R = O.synth_audio(n, 777, True)
     eng = OracleEngine(O, [c0], (1,), T, F, max_tiles=1)
     parts = stream.separate_stream(eng, L, R, rank, world)
+    sp, whole = stream.separate_host_range(eng, L, R, rank, world)                 # the configs[3] driver's per-rank call
+    parts_range = [(sp.out_offset, whole)]
     gathered = [None] * world
-    dist.all_gather_object(gathered, (float(np.abs(c0).sum()), parts))
+    dist.all_gather_object(gathered, (float(np.abs(c0).sum()), parts, parts_range))
     if rank == 0:
         q.put(gathered)
     dist.barrier()
@@ -99,3 +124,5 @@ def test_two_rank_sharding_matches_unsharded(oracle, coeffs):
     ref = oracle.istft(re, im)
     assert got.shape[2] == ref.shape[1]
     assert np.abs(got[0] - ref).max() <= 2e-6 * np.abs(ref).max()                    # only the overlap-add order differs
+    got2 = stream.stitch([pt for g in gathered for pt in g[2]], n, 1)                # one span per rank (scripts/stream_c4.py)
+    assert np.abs(got2[0] - ref).max() <= 2e-6 * np.abs(ref).max()
