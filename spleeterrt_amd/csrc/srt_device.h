@@ -118,9 +118,10 @@ __device__ __forceinline__ int srt_xcd_order(int total)
 struct SrtBlockCoord { int sp, mblk, stem, grp, ks; };
 // order: w = (stem, mblk) slowest, then instance group, then spatial tile (fastest: neighbours share halo rows)
 // ksplit > 1 (split-K launches): the K slice is the fastest index, so the workgroups that share one input patch are neighbours
-__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp, int ksplit = 1)
+// dual > 1 (two-tile workgroups): workgroup w owns the neighbouring tiles dual*w + sub of the same order
+__device__ __forceinline__ SrtBlockCoord srt_block_coord(int nsp, int nmb, int nstem, int ngrp, int ksplit = 1, int dual = 1, int sub = 0)
 {
-    const int pos0 = srt_xcd_order(nsp * nmb * nstem * ngrp * ksplit);
+    const int pos0 = srt_xcd_order(nsp * nmb * nstem * ngrp * ksplit / dual) * dual + sub;
     SrtBlockCoord c;
     c.ks = pos0 % ksplit;
     const int pos = pos0 / ksplit;

@@ -116,8 +116,15 @@ __device__ __forceinline__ void srt_mfma_pipeline_valu()
 //   12 = the same as one fenced burst after 40 % of the chunk's MFMAs
 //   13 = fenced, one staged float4 (4 values) at a time, spread over the remaining 60 %
 //   14 = fenced, one value at a time (~12 VALU: fits the issue shadow of the wave's own previous MFMA)
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0, bool SPLITK = false>
-__global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
+// DUAL: one 512-thread workgroup = two 4-wave groups, each running this kernel's program on its OWN output tile and its own
+// half of the LDS, one barrier phase apart: while one group issues the MFMAs of a chunk the other stages its next patch
+// (global -> registers -> BN/activation -> LDS) and then waits at the barrier, so every SIMD always has exactly one wave
+// feeding its matrix pipe.  Two independent 256-thread workgroups per CU do the same work but nothing keeps them out of
+// step: their staging phases (between two barriers, no MFMA) tend to coincide and the pipe idles (MI355X_MICROARCH.md,
+// "Two waves per SIMD").  The phase shift is one extra s_barrier executed by group 1 before its loop and by group 0 after its
+// epilogue; the barriers inside the loop are workgroup-wide and keep both the pairing and the in-group ordering.
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0, bool SPLITK = false, bool DUAL = false>
+__global__ void __launch_bounds__(DUAL ? 512 : 256, 2) srt_enc_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
@@ -135,23 +142,26 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     // the MFMAs of chunk ch instead of running under them (this was the "fixed cost" of every encoder layer: 10-15 %).
     // (every byte counts: down6's tile is 81 664 B, and two workgroups per CU must fit in 163 840 B)
     constexpr int NEPI = STEMSTACK ? 3 * BM : BM, NIBN = STEMSTACK ? 0 : 2 * SRT_ENC_MAX_CIN;
-    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + NEPI + NIBN];
+    constexpr int LDSF = KC * CHS + 2 * WSLAB + NEPI + NIBN;                        // floats per 4-wave group
+    __shared__ __attribute__((aligned(16))) float s_all[(DUAL ? 2 : 1) * LDSF];
 #ifndef SRT_TUNING
-    static_assert(sizeof(s_mem) * 2 <= 160 * 1024, "two workgroups per CU");       // every shipped tile shape; the measurement build has larger ones
+    static_assert(sizeof(float) * LDSF * 2 <= 160 * 1024, "two 4-wave groups per CU");   // every shipped tile shape; the measurement build has larger ones
 #endif
+    const int grp = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    float* s_mem = s_all + grp * LDSF;
     float* s_epi = s_mem + KC * CHS + 2 * WSLAB;        // bias (| BN scale | BN shift: down1 in fp16-storage mode) of this workgroup's BM rows
     float* s_ibn = s_epi + NEPI;                        // BN scale | shift of the INPUT channels (the producer stored conv + bias only)
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
 
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x & 255, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
     const int mtot = STEMSTACK ? p.stack * p.Cout : p.Cout;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (mtot + BM - 1) / BM, STEMSTACK ? 1 : p.nstems, groups, SPLITK ? p.ksplit : 1);
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (mtot + BM - 1) / BM, STEMSTACK ? 1 : p.nstems, groups, SPLITK ? p.ksplit : 1, DUAL ? 2 : 1, grp);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
@@ -297,6 +307,7 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
     srt_dma_slab<WROWS, BM>(wp + (size_t)chA * KC * 25 * CPW, CPW, s_w + (chA & 1) * WSLAB, wave, lane);
     load_patch(chA * KC);
     if (XF_LOOP) xform_pin(chA * KC);
+    if (DUAL && grp == 1) __builtin_amdgcn_s_barrier();    // one phase behind group 0 (pairs with its first loop barrier)
     for (int ch = chA; ch < nchunks; ++ch) {
         // A wave that stages (input BN + activation, LDS stores) outranks the co-resident workgroup's MFMA stream for VALU issue:
         // the staging phase sits between two barriers, so every cycle it loses to the other workgroup delays all four waves
@@ -399,12 +410,13 @@ __global__ void __launch_bounds__(256, 2) srt_enc_mfma2(const SrtConvParams p)
             }
         }
     }
+    if (DUAL && grp == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last loop barrier (its last MFMA segment ran beside this epilogue)
 }
 
 // ------------------------------------------------------------------------------------------- decoder v2
 // CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
-template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0, bool SPLITK = false>
-__global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
+template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0, bool SPLITK = false, bool DUAL = false>
+__global__ void __launch_bounds__(DUAL ? 512 : 256, 2) srt_dec_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
@@ -417,17 +429,20 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     constexpr int WROWS = KC * NTAP, WSLAB = (WROWS * BM + 255) / 256 * 256;
 
     constexpr bool EPI_LDS = ABL == 20;                  // tuning: bias / BN constants staged in LDS before the K loop (same LDS object)
-    __shared__ __attribute__((aligned(16))) float s_mem[KC * CHS + 2 * WSLAB + (EPI_LDS ? 3 * BM : 0)];
+    constexpr int LDSF = KC * CHS + 2 * WSLAB + (EPI_LDS ? 3 * BM : 0);             // floats per 4-wave group (DUAL: see srt_enc_mfma2)
+    __shared__ __attribute__((aligned(16))) float s_all[(DUAL ? 2 : 1) * LDSF];
+    const int grp = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    float* s_mem = s_all + grp * LDSF;
     float* s_in = s_mem;
     float* s_w = s_mem + KC * CHS;
     float* s_epi = s_mem + KC * CHS + 2 * WSLAB;
 
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x & 255, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, CLASSSTACK ? 1 : (p.Cout + BM - 1) / BM, p.nstems, groups, SPLITK ? p.ksplit : 1);
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, CLASSSTACK ? 1 : (p.Cout + BM - 1) / BM, p.nstems, groups, SPLITK ? p.ksplit : 1, DUAL ? 2 : 1, grp);
     const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
     const int m0 = bc.mblk * BM;
     const int stem = bc.stem, tile0 = bc.grp * NI;
@@ -500,6 +515,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
     const int chA = SPLITK ? bc.ks * cps : 0, nchunks = SPLITK ? min(nchunks_all, chA + cps) : nchunks_all;
     srt_dma_slab<WROWS, BM>(wp + (size_t)chA * KC * NTAP * CPW, CPW, s_w + (chA & 1) * WSLAB, wave, lane);
     load_patch(chA * KC);
+    if (DUAL && grp == 1) __builtin_amdgcn_s_barrier();    // one phase behind group 0
     for (int ch = chA; ch < nchunks; ++ch) {
         if ((ABL != 1 && ABL != 4) || ch == 0) store_patch();
         if (ABL != 2) __syncthreads();
@@ -600,6 +616,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma2(const SrtConvParams p)
             }
         }
     }
+    if (DUAL && grp == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last loop barrier
 }
 
 
@@ -816,6 +833,15 @@ static long srt_base_wgs(const SrtConvParams& p, int H, int W, int TH, int TW, i
 #ifdef SRT_TUNING
 static int tune(const char* key);
 #endif
+// Two-tile (512-thread, phase-shifted) workgroups exist in the measurement build only (SRT_TUNE=dual=1): strict alternation of
+// the two 4-wave groups measured 2-4.5 % SLOWER than two free-running workgroups per CU (up2-4 1.51-1.58 -> 1.58-1.65 ms,
+// encoders +1-3 %) - a single wave per SIMD in its MFMA segment stalls on its own LDS operand reads, which a second MFMA-phase
+// wave otherwise covers.
+#ifdef SRT_TUNING
+static bool srt_use_dual() { return tune("dual") != 0; }
+#else
+constexpr bool srt_use_dual() { return false; }
+#endif
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
 {
@@ -834,6 +860,13 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
         }
     }
 #endif
+#ifdef SRT_TUNING
+    constexpr int PWH_ = Enc2Pad<TW, SW>::value, LDSF_ = KC * NI * (2 * TH + 3) * 2 * PWH_ + 2 * ((KC * 25 * BM + 255) / 256 * 256) + BM + 2 * SRT_ENC_MAX_CIN;
+    if constexpr (!STK && LDSF_ * 8 <= 160 * 1024) if (srt_use_dual() && grid.x % 2 == 0 && grid.x >= 1024) {   // two-tile workgroups (see srt_enc_mfma2, DUAL)
+        hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 0, false, true>), dim3(grid.x / 2), dim3(512), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#endif
     hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -845,6 +878,12 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
 #ifdef SRT_TUNING
     if constexpr (!STK) if (tune("decx") == 20) {
         hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 20>), grid, dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#endif
+#ifdef SRT_TUNING
+    if constexpr (!STK) if (srt_use_dual() && grid.x % 2 == 0 && grid.x >= 1024) {
+        hipLaunchKernelGGL((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 0, false, true>), dim3(grid.x / 2), dim3(512), 0, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
 #endif
