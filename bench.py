@@ -73,8 +73,8 @@ def synth_weights(stem, device):
 
 def cpu_baseline(sample_tiles=None):
     """Reference CPU path (oracle/_ref: the reference's own C compiled from /root/reference, CPU_GEMM=1 naive GEMM)
-    on a bounded sample: tile-parallel like processMT (main.c:544-673) — one pthread-equivalent per tile, each running
-    the 4 sub-net forwards of its tile with the sequential GEMM — plus the reference stft/istft of the same span."""
+    on a bounded sample: tiles fanned out over threads like processMT (main.c:544-673) — one forward (tile, sub-network) with
+    the sequential GEMM per thread, every host core busy — plus the reference stft/istft of the same span."""
     os.environ.setdefault("OMP_NUM_THREADS", "1")          # tile-level parallelism only, as processMT does
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as O
@@ -89,8 +89,10 @@ def cpu_baseline(sample_tiles=None):
         nproc_avail = nproc
     if O.ref_path(flavour) is None:
         return {"value": None, "unit": "frames/s", "cores": 0, "nproc": nproc, "cpu_model": model, "kind": "reference", "sample": "oracle/_ref not built"}
-    cores = nproc_avail                                     # every host core this process may run on: one tile per thread
-    ntiles = sample_tiles or min(max(cores, 16), 256)       # bounded sample: ~10-30 s of CPU work
+    cores = nproc_avail                                     # every host core this process may run on
+    # bounded sample (~10-30 s of CPU work): one (tile, sub-network) forward per thread keeps every core busy with a quarter of
+    # the tiles a one-tile-per-thread split would need (a forward of the naive GEMM takes ~9 s on one core)
+    ntiles = sample_tiles or min(max((cores + STEMS - 1) // STEMS, 16), 256)
     coeffs = [O.synth_coeff(s) for s in range(STEMS)]
     n = ntiles * T * HOP
     L, R = O.synth_audio(n, 777, True)
@@ -100,16 +102,15 @@ def cpu_baseline(sample_tiles=None):
     t_stft = time.time() - t0
     mags = [O.magnitude_tile(re, im, j * T, T, F) for j in range(ntiles)]
 
-    def work(j):
-        out = []
-        for s in range(STEMS):
-            net = O.RefNet(coeffs[s], F, T, 1, flavour)
-            out.append(net(mags[j]))
-            net.close()
-        return out
+    def work(js):
+        j, s = js
+        net = O.RefNet(coeffs[s], F, T, 1, flavour)
+        y = net(mags[j])
+        net.close()
+        return y
     t0 = time.time()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(ntiles)))
+        list(ex.map(work, [(j, s) for j in range(ntiles) for s in range(STEMS)]))
     t_nn = time.time() - t0
     t0 = time.time()
     for s in range(STEMS):
@@ -121,7 +122,7 @@ def cpu_baseline(sample_tiles=None):
     return {"value": frames / total, "unit": "frames/s", "x_realtime": frames * HOP / FS / total, "cores": cores, "nproc": nproc,
             "cpu_model": model, "kind": kind,
             "sample": "%d tiles x %d stems (%d frames): stft %.2fs + nn %.2fs + istft %.2fs; %s build of the reference C "
-                      "(naive CPU_GEMM=1 GEMM, no MKL), one tile per thread as processMT" % (ntiles, STEMS, frames, t_stft, t_nn, t_istft, flavour)}
+                      "(naive CPU_GEMM=1 GEMM, no MKL), tiles fanned out over threads as processMT does, one (tile, sub-network) forward per thread" % (ntiles, STEMS, frames, t_stft, t_nn, t_istft, flavour)}
 
 
 def main():

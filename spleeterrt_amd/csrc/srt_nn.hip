@@ -572,9 +572,15 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // of the input tile + 1-pixel halo), the 25 x N result goes to LDS only, and each input pixel's 2x2 output quad then
 // GATHERS its taps from LDS (no scatter, no atomics) with bias -> act -> BN fused.  B operands come straight from
 // global memory (every element feeds exactly one MFMA, so LDS staging would buy nothing).
+// IN16: the two source tensors hold halves (fp16 activation storage).  The contraction then runs on v_mfma_f32_32x32x16_f16
+// (two MFMAs per 32-pixel sub-tile instead of sixteen fp32 ones: the 0.30 ms of matrix-pipe time this layer does not overlap
+// with its loads drops to 0.02 ms); the fp16 values are used as they are, the weights are rounded to fp16 (exact for the
+// reference's fp16 model container), accumulation and the epilogue stay fp32.
+typedef _Float16 srt_h8 __attribute__((ext_vector_type(8)));
 template <int TH, int TW, int CIN, bool IN16 = false>
 __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
 {
+    static_assert(!IN16 || CIN == 32, "the fp16 form is written for two 16-channel k-groups");
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
     __shared__ float s_col[25 * NPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -588,16 +594,29 @@ __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* w = p.wraw + stem * p.coeff_stem;               // [Cin][1][25]
-    float a[CIN / 2];
+    // fp32 form: k-pair = channels (2cp, 2cp+1); fp16 form: k-group kg = channels 16kg..16kg+15, lane half g holds 8 of them
+    float a[IN16 ? 1 : CIN / 2];
+    srt_h8 a16[IN16 ? 2 : 1];
+    if (IN16) {
 #pragma unroll
-    for (int cp = 0; cp < CIN / 2; ++cp) {
-        const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
-        a[cp] = l31 < 25 ? v : 0.0f;
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = w[(kg * 16 + half * 8 + q) * 25 + min(l31, 24)];
+                a16[kg][q] = (_Float16)(l31 < 25 ? v : 0.0f);
+            }
+    } else {
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) {
+            const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
+            a[cp] = l31 < 25 ? v : 0.0f;
+        }
     }
     // A wave owns sub-tiles wave, wave+4, ...: the B fragments of ALL of them are requested up front (NW x 16 registers), so
     // the HBM latency is paid once per workgroup instead of once per sub-tile.
     constexpr int NW = (NSUB + 3) / 4;
-    float b[NW][CIN / 2];
+    float b[IN16 ? 1 : NW][CIN / 2];
+    srt_h8 b16[IN16 ? NW : 1][2];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int sub = wave + 4 * i;
@@ -605,11 +624,20 @@ __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
         const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
         const bool ok = sub < NSUB && pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         const size_t off = ok ? (size_t)gy * p.W + gx : 0;
+        if (IN16) {
 #pragma unroll
-        for (int cp = 0; cp < CIN / 2; ++cp) {
-            const float v = IN16 ? (float)srt_src_channel_t<_Float16>(p, stem, tile, 2 * cp + half, hw)[off]      // fp16 activation storage
-                                 : srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
-            b[i][cp] = ok ? v : 0.0f;
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const _Float16 v = srt_src_channel_t<_Float16>(p, stem, tile, kg * 16 + half * 8 + q, hw)[off];
+                    b16[i][kg][q] = ok ? v : (_Float16)0.0f;
+                }
+        } else {
+#pragma unroll
+            for (int cp = 0; cp < CIN / 2; ++cp) {
+                const float v = srt_src_channel(p, stem, tile, 2 * cp + half, hw)[off];
+                b[IN16 ? 0 : i][cp] = ok ? v : 0.0f;
+            }
         }
     }
 #pragma unroll
@@ -620,8 +648,13 @@ __global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if (IN16) {
 #pragma unroll
-            for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[i][cp], acc, 0, 0, 0);
+                for (int kg = 0; kg < 2; ++kg) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[kg], b16[IN16 ? i : 0][kg], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[IN16 ? 0 : i][cp], acc, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;

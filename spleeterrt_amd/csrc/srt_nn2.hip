@@ -395,16 +395,28 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, 2) srt_enc_mfma2(const SrtCo
             const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
             const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
             const size_t pbase = (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+            if (STEMSTACK && p.out16) {
+                // fp16 activation storage (down1 feeds the fp16-MFMA layers): raw and, for down2, act(bn(raw)) as halves.  (Pairing
+                // neighbouring lanes through DPP so that every store is 4 bytes halves the store instructions but not the 64-byte
+                // segments they touch: measured 12 % slower here, neutral in srt_enc_f16.)
+                _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+                _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && m < mlimit) {
+                        const float v = acc[mr][nr][r] + bi[r];
+                        rawh[ob[r] + pbase] = (_Float16)v;
+                        if (twoOut) acth[ob[r] + pbase] = (_Float16)srt_enc_epilogue(v, sc2[r], sf2[r], apg[r >> 3]);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pix_ok && m < mlimit) {
                     if (SPLITK) p.ws[(size_t)bc.ks * p.ws_slice + ob[r] + pbase] = acc[mr][nr][r];      // partial sum; bias is added by the reduce
-                    else if (STEMSTACK && p.out16) {                                            // fp16 activation storage (down1 feeds the fp16-MFMA layers)
-                        const float v = acc[mr][nr][r] + bi[r];
-                        reinterpret_cast<_Float16*>(p.outRaw)[ob[r] + pbase] = (_Float16)v;
-                        if (twoOut) reinterpret_cast<_Float16*>(p.outAct)[ob[r] + pbase] = (_Float16)srt_enc_epilogue(v, sc2[r], sf2[r], apg[r >> 3]);
-                    }
                     else p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
                 }
             }
@@ -892,7 +904,7 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
 }
 
 // Per-layer tile shapes.  Template arguments: <BM, WM, SW, NSX, NSY, NI, KC, stacked-M>.  The defaults below are the
-// measured best on MI355X at 64 tiles x 4 stems.  Building with -DSRT_TUNING (SRT_TUNING=1 python -m spleeterrt_amd.build)
+// measured best on MI355X at 64 tiles x 4 stems.  Building with -DSRT_TUNING (python -m spleeterrt_amd.build --tuning: a second library, selected with SPLEETERRT_LIB)
 // adds the alternatives that were measured against them and the ablation builds quoted in DESIGN.md section 6, selected at
 // run time by SRT_TUNE="key=value,..." (keys down1 down2 up4 up5 abl eabl); a default build contains only the table.
 #ifdef SRT_TUNING

@@ -423,16 +423,24 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
         const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
         const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
         const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+        if (A16) {
+            _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+            _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (pix_ok && m < p.Cout) {
+                    const float v = acc[nr][r] + bi[r];                                           // conv + bias: the skip tensor
+                    rawh[obase + (size_t)m * ohw] = (_Float16)v;
+                    if (twoOut) acth[obase + (size_t)m * ohw] = (_Float16)srt_enc_epilogue(v, sc[r], sf[r], actp);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (pix_ok && m < p.Cout) {
-                const float v = acc[nr][r] + bi[r];                                               // conv + bias: the skip tensor
-                if (A16) {
-                    reinterpret_cast<_Float16*>(p.outRaw)[obase + (size_t)m * ohw] = (_Float16)v;
-                    if (twoOut) reinterpret_cast<_Float16*>(p.outAct)[obase + (size_t)m * ohw] = (_Float16)srt_enc_epilogue(v, sc[r], sf[r], actp);
-                } else p.outRaw[obase + (size_t)m * ohw] = v;
-            }
+            if (pix_ok && m < p.Cout) p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];      // conv + bias, stored once
         }
     }
 }

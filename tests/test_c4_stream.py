@@ -110,3 +110,28 @@ def test_c4_sixty_minute_stream_one_gpu(oracle, coeffs):
             assert float(np.abs(A[s, c, off:off + 3072] - (p0[s, c, off:] + p1[s, c, :3072])).max()) <= tol
             assert float(np.abs(A[s, c, off + 3072:] - p1[s, c, 3072:]).max()) <= tol
     e64.close()
+
+
+def test_c4_driver_script_small_stream():
+    """scripts/stream_c4.py itself (the N-rank driver, here at world = 1) on a 30-second stream: its gathered output equals one
+    device-resident srtSeparate of the same stream, and its report carries the metric fields."""
+    import torch
+    import spleeterrt_amd as srt
+    import stream_c4
+    from bench import synth_weights
+    res, full = stream_c4.run(minutes=0.5, max_tiles=2, gather=True)
+    assert res["n_gpus"] == 1 and res["tiles"] == sum(res["tiles_per_rank"]) and res["checksum"]["finite"]
+    assert res["x_realtime_pcie_inclusive"] > 0 and res["bytes_d2h"] == full.size * 4
+    n_audio = int(round(0.5 * 60 * 44100))
+    n = 4096 * ((n_audio + 4095) // 4096) + 8192
+    L, R = stream_c4.synth_stream(n_audio)
+    Lp = np.zeros(n, np.float32); Rp = np.zeros(n, np.float32)
+    Lp[:n_audio] = L; Rp[:n_audio] = R
+    dev = torch.device("cuda", 0)
+    eng = srt.Engine(F=F, T=T, stem_modes=MODES, oob_weights=OOB, variant=srt.VARIANT_VST, max_tiles=res["tiles"], device=dev)
+    for s in range(S):
+        eng.set_coeff(s, synth_weights(s, dev))
+    ref = eng.separate(torch.from_numpy(Lp).cuda(), torch.from_numpy(Rp).cuda()).cpu().numpy()
+    eng.close()
+    assert ref.shape == full.shape
+    assert np.abs(full - ref).max() <= 1e-5 * np.abs(ref).max()      # chunk seams + (2-tile chunks) split-K association
