@@ -22,8 +22,8 @@ res = {"precision": prec_name}
 side = torch.cuda.Stream(device=dev)                      # graphs need a capturable (non-null) stream
 
 
-def timed(fn, K=50):
-    for _ in range(5):
+def timed(fn, K=100):
+    for _ in range(40):                                   # long enough for the clocks to come back up after the engine set-up
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -112,6 +112,7 @@ __device__ __forceinline__ void srt_mfma_pipeline_valu()
 
 // ABL (SRT_TUNING builds only; 0 = the shipped kernel): 1,3,4,5,7,8 timing ablations (wrong results);
 //   15 = no s_setprio around the staging phase (the shipped kernel raises the priority while a wave stages its patch)
+//   30 = compiled for three workgroups per CU (168 VGPRs; needs a tile whose LDS is <= 53 KB)
 //   11 = the input BN + activation is applied to the prefetched registers INSIDE the MFMA phase (VALU groups woven between MFMAs)
 //   12 = the same as one fenced burst after 40 % of the chunk's MFMAs
 //   13 = fenced, one staged float4 (4 values) at a time, spread over the remaining 60 %
@@ -124,7 +125,7 @@ __device__ __forceinline__ void srt_mfma_pipeline_valu()
 // "Two waves per SIMD").  The phase shift is one extra s_barrier executed by group 1 before its loop and by group 0 after its
 // epilogue; the barriers inside the loop are workgroup-wide and keep both the pairing and the in-group ordering.
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STEMSTACK, int ABL = 0, bool SPLITK = false, bool DUAL = false>
-__global__ void __launch_bounds__(DUAL ? 512 : 256, 2) srt_enc_mfma2(const SrtConvParams p)
+__global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_mfma2(const SrtConvParams p)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     constexpr int NS = NSX * NSY * NI, WN = 4 / WM, MR = BM / (32 * WM), NR = NS / WN;
@@ -1006,6 +1007,13 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     // same shape on down6 are slower).
     if (p.Cout >= 128 && Wo >= 64) return launch_enc2_cfg<128, 2, 32, 2, 4, 1, 2, false>(p, s);
     if (p.Cout >= 128 && Wo >= 32) return launch_enc2_cfg<128, 2, 32, 1, 8, 1, 2, false>(p, s);
+#ifdef SRT_TUNING
+    if (tune("occ3") && p.Cout >= 64 && Wo >= 64) {                                      // three workgroups per CU on two-channel chunks
+        dim3 grid(((Wo + 63) / 64) * ((p.H / 2 + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
+        hipLaunchKernelGGL((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, false, 30>), grid, dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#endif
     if (Wo >= 64) {                                                                      // down3 / down4 class
 #ifdef SRT_TUNING
         switch (tune("eabl")) {                                                          // 1 no loads, 3 constant operands, 4 no patch, 5 no DMA, 8 no scheduling hint
