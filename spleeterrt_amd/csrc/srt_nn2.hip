@@ -267,13 +267,21 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // down1 (stem-stacked, one K chunk, 64 stores per lane) is bound by its stores.  Which pixel an MFMA column computes is free to
+    // choose, so the NR sub-tiles of a wave are INTERLEAVED: lane l of sub-tile nr owns pixel NR*(l % (64/NR)) + nr of row
+    // l / (64/NR).  A lane then holds NR consecutive pixels of every channel row and the epilogue writes them as one 16-byte
+    // (8-byte) vector instead of NR scalars; the price is a 4-way bank conflict on the B-fragment reads (lane stride NR words),
+    // ~6 % of this kernel's time.
+    constexpr bool VECPIX = STEMSTACK && TW == 64 && SW == 32 && NI == 1 && (NR == 2 || NR == 4) && TH == WN * NR / 2;
+    constexpr int LPR = VECPIX ? 64 / NR : 1;            // lanes per tile row
     int boff[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int s = wn * NR + nr;
         const int il = s / (NSX * NSY), sy = (s / NSX) % NSY, sx = s % NSX;
-        const int oy = sy * SH + l31 / SW, ox = sx * SW + l31 % SW;
-        boff[nr] = half * CHS + il * INS + 2 * oy * ROWS + ox;
+        const int oy = VECPIX ? wn * (NR / 2) + l31 / LPR : sy * SH + l31 / SW;
+        const int ox = VECPIX ? NR * (l31 % LPR) + nr : sx * SW + l31 % SW;
+        boff[nr] = half * CHS + (VECPIX ? 0 : il * INS) + 2 * oy * ROWS + ox;
     }
     const int aoff = half * 25 * BM + wm * MR * 32 + l31;
 
@@ -389,6 +397,32 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
         }
         const SrtAct apg[2] = { srt_act_params(STEMSTACK && ((p.elu_mask >> stg[0]) & 1u) ? SRT_ACT_ELU : p.act, p.variant),
                                 srt_act_params(STEMSTACK && ((p.elu_mask >> stg[1]) & 1u) ? SRT_ACT_ELU : p.act, p.variant) };
+        if (VECPIX) {                                  // one vector store of NR consecutive pixels per channel row (see boff)
+            typedef float vecf __attribute__((ext_vector_type(NR)));
+            typedef _Float16 vech __attribute__((ext_vector_type(NR)));
+            const int oy = ty0 + wn * (NR / 2) + l31 / LPR, ox0 = tx0 + NR * (l31 % LPR);
+            const bool pix_ok = tile0 < p.ntiles && oy < Ho && ox0 + NR - 1 < Wo;
+            const size_t pbase = (pix_ok ? tile0 : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox0 : 0);
+            _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+            _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pix_ok && m < mlimit) {
+                    vecf v;
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) v[nr] = acc[mr][nr][r] + bi[r];
+                    if (p.out16) {                     // fp16 activation storage: raw and, for down2, act(bn(raw)) as halves
+                        vech hv, ha;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) { hv[nr] = (_Float16)v[nr]; ha[nr] = (_Float16)srt_enc_epilogue(v[nr], sc2[r], sf2[r], apg[r >> 3]); }
+                        *reinterpret_cast<vech*>(rawh + ob[r] + pbase) = hv;
+                        if (twoOut) *reinterpret_cast<vech*>(acth + ob[r] + pbase) = ha;
+                    } else *reinterpret_cast<vecf*>(p.outRaw + ob[r] + pbase) = v;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int s = wn * NR + nr;
