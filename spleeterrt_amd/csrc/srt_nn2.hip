@@ -91,32 +91,14 @@ __device__ __forceinline__ void srt_mfma_pipeline()
     }
 }
 
-// The same with VALU groups woven into the second part of the chunk body: NV VALU instructions after every M1 + M2 MFMAs
-// once VSTART MFMAs have been issued.  Used by the variant that applies the input batch-norm + activation to the PREFETCHED
-// registers of the next chunk while this chunk's MFMAs run: each VALU group fits in the issue shadow of the wave's own MFMA,
-// and it starts late enough for the prefetch to have landed (the first group carries the s_waitcnt vmcnt).
-template <int NMFMA, int PRO, int M1, int M2, int NV, int VSTART>
-__device__ __forceinline__ void srt_mfma_pipeline_valu()
-{
-#pragma unroll
-    for (int i = 0; i < PRO; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-    for (int i = 0; i < NMFMA / (M1 + M2); ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, M1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, M2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i * (M1 + M2) >= VSTART) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-    }
-}
-
 // ABL (SRT_TUNING builds only; 0 = the shipped kernel): 1,3,4,5,7,8 timing ablations (wrong results);
 //   15 = no s_setprio around the staging phase (the shipped kernel raises the priority while a wave stages its patch)
 //   30 = compiled for three workgroups per CU (168 VGPRs; needs a tile whose LDS is <= 53 KB)
-//   11 = the input BN + activation is applied to the prefetched registers INSIDE the MFMA phase (VALU groups woven between MFMAs)
-//   12 = the same as one fenced burst after 40 % of the chunk's MFMAs
-//   13 = fenced, one staged float4 (4 values) at a time, spread over the remaining 60 %
-//   14 = fenced, one value at a time (~12 VALU: fits the issue shadow of the wave's own previous MFMA)
+//   (11-14, removed: the input BN + activation applied to the prefetched registers inside the MFMA phase - as scheduling groups, one
+//    fenced burst, per float4 or per value - measured 0-1 % slower than the transform in store_patch)
+//   (40, removed: a wave owning NR vertically stacked sub-tiles so that one B fragment - input row rho, column variant kx - serves up
+//    to three taps of three sub-tiles: 55 instead of 100 fragment reads per channel pair, 9 instead of 61 s_waitcnt in the chunk
+//    body.  Measured: down2 +3 %, down3-5 within 1 %.  The LDS operand reads are not what the encoders lose.)
 // DUAL: one 512-thread workgroup = two 4-wave groups, each running this kernel's program on its OWN output tile and its own
 // half of the LDS, one barrier phase apart: while one group issues the MFMAs of a chunk the other stages its next patch
 // (global -> registers -> BN/activation -> LDS) and then waits at the barrier, so every SIMD always has exactly one wave
@@ -193,7 +175,6 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
     // Padding stays exactly zero (the select comes after the transform).  The constants are chunk-uniform per staged
     // element (its channel is fixed, only the chunk base moves) and sit in LDS.
     const bool xform = !STEMSTACK && p.inScale != nullptr;
-    constexpr bool XF_LOOP = !STEMSTACK && ABL >= 11 && ABL <= 14;        // transform inside the MFMA phase (launcher guarantees inScale)
     float4 pin[NLD];
     auto load_patch = [&](int c0) {
         const float* base = srcBase + (size_t)c0 * hw;
@@ -204,7 +185,7 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
         }
     };
     auto store_patch = [&](int c0) {
-        if (xform && !XF_LOOP) {                                               // one uniform ELU / non-ELU branch around all NLD elements
+        if (xform) {                                                           // one uniform ELU / non-ELU branch around all NLD elements
             float sc[NLD], sf[NLD];
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
@@ -235,28 +216,6 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
                 *reinterpret_cast<float2*>(d + PWH) = make_float2(v.y, v.w);      // odd columns  -> plane 1
             }
         }
-    };
-
-    // branch-free (the chunk body must stay one basic block for the scheduling groups): the exp is evaluated for every stem kind
-    auto xform_pin = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const bool ok = goff[i] >= 0;                                      // padding: scale = shift = 0 -> act(0) = 0
-            const float sc0 = s_ibn[c0 + cix[i]], sf0 = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
-            const float sc = ok ? sc0 : 0.0f, sf = ok ? sf0 : 0.0f;
-            pin[i].x = srt_enc_epilogue(pin[i].x, sc, sf, actp);
-            pin[i].y = srt_enc_epilogue(pin[i].y, sc, sf, actp);
-            pin[i].z = srt_enc_epilogue(pin[i].z, sc, sf, actp);
-            pin[i].w = srt_enc_epilogue(pin[i].w, sc, sf, actp);
-        }
-    };
-
-    auto xform_comp = [&](int i, int comp, int c0) {       // one staged value (compile-time i, comp)
-        const bool ok = goff[i] >= 0;
-        const float sc0 = s_ibn[c0 + cix[i]], sf0 = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
-        const float sc = ok ? sc0 : 0.0f, sf = ok ? sf0 : 0.0f;
-        float& x = comp == 0 ? pin[i].x : (comp == 1 ? pin[i].y : (comp == 2 ? pin[i].z : pin[i].w));
-        x = srt_enc_epilogue(x, sc, sf, actp);
     };
 
     f32x16 acc[MR][NR];
@@ -315,7 +274,6 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
     const int chA = SPLITK ? bc.ks * cps : 0, nchunks = SPLITK ? min(nchunks_all, chA + cps) : nchunks_all;
     srt_dma_slab<WROWS, BM>(wp + (size_t)chA * KC * 25 * CPW, CPW, s_w + (chA & 1) * WSLAB, wave, lane);
     load_patch(chA * KC);
-    if (XF_LOOP) xform_pin(chA * KC);
     if (DUAL && grp == 1) __builtin_amdgcn_s_barrier();    // one phase behind group 0 (pairs with its first loop barrier)
     for (int ch = chA; ch < nchunks; ++ch) {
         // A wave that stages (input BN + activation, LDS stores) outranks the co-resident workgroup's MFMA stream for VALU issue:
@@ -326,11 +284,7 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
         __syncthreads();                                   // patch(ch) visible; DMA(ch) landed (vmcnt(0) precedes the barrier)
         if (ABL != 15) __builtin_amdgcn_s_setprio(0);
         const float* sw = s_w + (ch & 1) * WSLAB;
-        const int cn = min(ch + 1, nchunks - 1);           // XF_LOOP: unconditional prefetch (a redundant reload at the end) keeps the body branch-free
-        if (XF_LOOP) {
-            srt_dma_slab<WROWS, BM>(wp + (size_t)cn * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
-            load_patch(cn * KC);
-        } else if (ch + 1 < nchunks && ABL != 1) {       // issued up front; spreading the pieces between the MFMAs measured no gain
+        if (ch + 1 < nchunks && ABL != 1) {              // issued up front; spreading the pieces between the MFMAs measured no gain
             if (ABL != 5) srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
             if (ABL != 4) load_patch((ch + 1) * KC);
         }
@@ -349,28 +303,7 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
-                if (ABL >= 12 && ABL <= 14) {
-                    constexpr int NSTEP = (KC / 2) * 25, K0 = NSTEP * 2 / 5, NCOMP = 4 * NLD;
-                    constexpr int PER = ABL == 12 ? NCOMP : (ABL == 13 ? 4 : 1);          // values transformed per insertion point
-                    constexpr int NPT = NCOMP / PER, STRIDE = (NSTEP - 1 - K0) / NPT > 0 ? (NSTEP - 1 - K0) / NPT : 1;
-                    const int k = cp * 25 + tap;
-                    if (k >= K0 && (k - K0) % STRIDE == 0 && (k - K0) / STRIDE < NPT) {
-                        const int pt = (k - K0) / STRIDE;
-                        __builtin_amdgcn_sched_barrier(0x3F4);                             // memory + SALU may cross, VALU / MFMA stay put
-#pragma unroll
-                        for (int q = pt * PER; q < pt * PER + PER; ++q) xform_comp(q / 4, q % 4, cn * KC);
-                        __builtin_amdgcn_sched_barrier(0x3F4);
-                    }
-                }
             }
-        }
-        if (ABL == 11) {
-            xform_pin(cn * KC);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i)                  // keep the transform on this side of the barrier (LLVM sinks it to its use otherwise)
-                asm volatile("" : "+v"(pin[i].x), "+v"(pin[i].y), "+v"(pin[i].z), "+v"(pin[i].w));
-            constexpr int NM = (KC / 2) * 25 * MR * NR;
-            srt_mfma_pipeline_valu<NM, 16, 1, 2, (NLD * 4 * 12 + (NM * 3 / 5) / 3 - 1) / ((NM * 3 / 5) / 3), NM * 2 / 5>();
         }
         if (ABL == 0 || ABL == 15) srt_mfma_pipeline<(KC / 2) * 25 * MR * NR, 16, 1, 2>();
         __syncthreads();                                   // everyone is done with s_in and slab (ch&1)
@@ -897,13 +830,9 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
     const int mtot = STK ? p.stack * p.Cout : p.Cout;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((mtot + BM - 1) / BM) * (STK ? 1 : p.nstems) * ((p.ntiles + NI - 1) / NI));
 #ifdef SRT_TUNING
-    if constexpr (!STK) if (p.inScale) {                  // where the input BN + activation runs: encx = 11..15 (see srt_enc_mfma2)
+    if constexpr (!STK) if (p.inScale) {                  // where the input BN + activation runs: encx = 15 (see srt_enc_mfma2)
         switch (tune("encx")) {
         case 15: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 15>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 11: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 11>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 12: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 12>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 13: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 13>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 14: hipLaunchKernelGGL((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 14>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
 #endif
