@@ -39,11 +39,11 @@ LAYER_FLOP["up7"] = 2 * 2 * 16 * T * F
 assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
 # kernel symbol (as rocprofv3 prints it) that runs each layer at T=256, F=1024; layers sharing a symbol have equal FLOPs
 LAYER_SYMBOL = {
-    "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 2, false, 0, false>",
-    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false>", "down4": "srt_enc_mfma2<128, 2, 32, 2, 4, 1, 2, false, 0, false>",
-    "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false>",
-    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false>",
-    "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0, false>",
+    "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false, false>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 2, false, 0, false, false>",
+    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false, false>", "down4": "srt_enc_mfma2<128, 2, 32, 2, 4, 1, 2, false, 0, false, false>",
+    "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false, false>",
+    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false, false>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false, false>",
+    "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false, false>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0, false, false>",
     "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",
 }
 # written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first)
@@ -245,9 +245,12 @@ def main():
         dom_flop = sym_flop[dom] / sym_n[dom]
         dom_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
         traffic = mfma_busy = pmc_file = None
+        def _norm(sym):                                     # kernel symbol without its trailing mode flags (they grow with the code)
+            return ",".join(sym.split(",")[:8])
         for pf in PMC_SUMMARIES:
             try:
-                pm = json.load(open(pf)).get(dom)
+                allpm = json.load(open(pf))
+                pm = allpm.get(dom) or next((v for k, v in allpm.items() if _norm(k) == _norm(dom)), None)
                 if pm and a.tiles == TILES:
                     traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
                     # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs; 64 per v_mfma_f32_32x32x2_f32)

@@ -83,7 +83,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
             dist.broadcast(w, 0)
         eng.set_coeff(s, w)
     torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t_b0
+    t_bcast = time.perf_counter() - t_b0                          # synthesis on rank 0 + broadcast + GEMM packing (outside the timed region)
 
     # this rank's span of the stream, generated in place into page-locked memory (a rank never touches the rest)
     sp = stream.rank_span(n, T, rank, world)
@@ -152,7 +152,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
             "seconds": dt, "frames_per_s": frames / dt, "x_realtime_pcie_inclusive": frames * HOP / FS / dt,
             "timed_region": "page-locked host PCM -> H2D -> STFT/U-Nets/mask/iSTFT -> D2H page-locked host stems, max over ranks, %d repeat(s) after one warm-up pass" % repeats,
             "bytes_h2d": 2 * 4 * n, "bytes_d2h": STEMS * 2 * 4 * (rows * HOP + 3072),
-            "weight_broadcast_s": t_bcast, "collect_on_rank0_s": t_gather if gather else None,
+            "weight_setup_s": t_bcast, "collect_on_rank0_s": t_gather if gather else None,
             "collective": "broadcast of %d weight blobs (39.29 MB each) only" % STEMS,
         }
         if full is not None:

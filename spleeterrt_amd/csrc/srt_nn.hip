@@ -760,6 +760,9 @@ int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
 {
     if (p.W % 4 == 0) {
         size_t bx4 = ((size_t)p.H * (p.W / 4) + 255) / 256;
+#ifdef SRT_TUNING
+        if (const char* tv = getenv("SRT_TUNE_HEAD")) { const int it = atoi(tv); if (it > 1) bx4 = (bx4 + it - 1) / it; }   // pixels-per-thread sweep
+#endif
         if (bx4 > 65535) bx4 = 65535;
         const unsigned grid = (unsigned)bx4 * p.nstems * p.ntiles;
         if (p.variant == 0) hipLaunchKernelGGL(srt_head_kernel4<true>, dim3(grid), dim3(256), 0, s, p);
