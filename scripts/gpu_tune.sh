@@ -1,25 +1,25 @@
 #!/bin/bash
-# One gpurun call: quick parity subset + headline bench + tuning variants.  bash scripts/gpu_tune.sh <tag> "<SRT_TUNE settings separated by ;>"
+# One gpurun call that measures kernel variants of the tuning library (python -m spleeterrt_amd.build --tuning) against the product
+# library on the same box:   bash scripts/gpu_tune.sh <tag> <f32|f16|f16x2> "SRT_TUNE=decx=20;SRT_TUNE=bm128=1;SRT_TUNE16=1;SRT_TUNE_HEAD=2"
+# Prints one line per setting: ms per 64-tile step and the per-layer kernel times (HIP events).  Keys: csrc/srt_nn2.hip (SRT_TUNE=key=value,...:
+# down1 down2 up4 up5 abl eabl encx decx bm128 occ3 dual), csrc/srt_nn3.hip (SRT_TUNE16), csrc/srt_nn.hip (SRT_TUNE_UP6, SRT_TUNE_HEAD).
 set -u
-TAG=${1:-r02b}
+TAG=${1:-tune}; PREC=${2:-f32}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "forward_layers or separate_end_to_end or fp16_mfma or full_size or geometry" ) > $OUT/pytest.log 2>&1
-tail -4 $OUT/pytest.log
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
-python - <<PY
-import json
-d=json.load(open("$OUT/bench.json")); print("default", round(d["ms_per_step"],3), d["kernel_ms"])
-PY
-export SPLEETERRT_LIB=$PWD/spleeterrt_amd/libspleeterrt_amd_tuning.so
-IFS=';' read -ra SETS <<< "${2:-}"
-for t in "${SETS[@]}"; do
-  SRT_TUNE="$t" timeout 200 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > $OUT/bench_$t.json 2>> $OUT/bench.err
+run() {   # label, env assignment (may be empty)
+  env $2 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision $PREC > "$OUT/bench_$1.json" 2>> $OUT/bench.err
   python - <<PY
 import json
 try:
-    d=json.load(open("$OUT/bench_$t.json")); print("$t".ljust(20), round(d["ms_per_step"],3), d["kernel_ms"])
-except Exception as e: print("$t", "failed", e)
+    d = json.load(open("$OUT/bench_$1.json")); print("$1".ljust(28), round(d["ms_per_step"], 3), d["kernel_ms"])
+except Exception as e:
+    print("$1", "failed", e)
 PY
-done
+}
+run product ""
+export SPLEETERRT_LIB=$PWD/spleeterrt_amd/libspleeterrt_amd_tuning.so
+run tuning-default ""
+IFS=';' read -ra SETS <<< "${3:-}"
+for t in "${SETS[@]}"; do run "$t" "$t"; done
