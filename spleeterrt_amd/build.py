@@ -21,6 +21,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # csrc/srt_nn2.hip); a default build holds only the shipped configuration.
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-fvisibility=hidden"]
 SO_TUNING = os.path.join(PKG, "libspleeterrt_amd_tuning.so")
+# per-file flags.  srt_nn4.hip: no SLP vectorisation - packed f32 adds (v_pk_add_f32) beside MFMAs cost more than the two scalar adds
+# they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and its transform arithmetic is issued in the MFMAs' shadow.
+FILE_FLAGS = {"srt_nn4.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -50,7 +53,7 @@ def build(force=False, verbose=True, tuning=False):
         if force or _stale(obj, [src] + hdrs):
             if verbose:
                 print("[build] hipcc -c", os.path.basename(src), "(tuning)" if tuning else "", flush=True)
-            procs.append((src, subprocess.Popen([HIPCC] + flags + ["-c", src, "-o", obj])))
+            procs.append((src, subprocess.Popen([HIPCC] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)

@@ -89,6 +89,7 @@ struct srt_engine {
     size_t wpack16_down_stem[6], wpack16_up_stem[6];
     float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
+    float* wino_u[6]; size_t wino_u_stem[6];           // Winograd-transformed decoder weights (srt_nn4.hip), layers in srt_wino_mask() only
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
     size_t raw_tile[6], up_tile[6];                    // elements per instance
@@ -161,6 +162,7 @@ static void free_all(srt_engine* e)
     if (e->ws) hipFree(e->ws);
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
+    for (int i = 0; i < 6; ++i) if (e->wino_u[i]) hipFree(e->wino_u[i]);
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
     for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act16buf[i]) hipFree(e->act16buf[i]); }
     void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->spec2, e->mag, e->masks, e->frames };
@@ -182,6 +184,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     e->graph_mode = 0; e->gclock = 0; memset(e->gslots, 0, sizeof e->gslots);
     if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail(-3, "srtCreate: no current HIP device"); }
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
+    memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -207,6 +210,12 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
         e->wpack_up_stem[i] = (size_t)e->lo.up[i].cin * 25 * e->lo.up[i].cp;
         EALLOC(e->wpack_down[i], S * e->wpack_down_stem[i]);
         EALLOC(e->wpack_up[i], S * e->wpack_up_stem[i]);
+        // Winograd form of the decoder layers named by srt_wino_mask() (fp32 MFMA path): [Cin/4][Cout/16][4][16][52] per stem
+        const LayerOff& U = e->lo.up[i];
+        if (cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && ((srt_wino_mask() >> i) & 1) && U.cout % 16 == 0 && U.cin % 4 == 0) {
+            e->wino_u_stem[i] = (size_t)U.cin * U.cout * 52;
+            EALLOC(e->wino_u[i], S * e->wino_u_stem[i]);
+        }
     }
     // fp16 activation storage: every layer between down1 and up6 must run on the fp16-MFMA kernels, which stage aligned
     // 4-pixel row segments at every level (up1's input is F/64 wide): F % 256 == 0.  Other geometries keep fp32 tensors.
@@ -264,6 +273,7 @@ static int pack_stem(srt_engine* e, int stem)
         if (srt_launch_pack_dec(c + U.w, e->wpack_up[i] + stem * e->wpack_up_stem[i], U.cin, U.cout, U.cp, e->stream)) return fail(-2, "pack launch failed");
         if (e->wpack16_down[i] && srt_launch_pack16(c + D.w, e->wpack16_down[i] + stem * e->wpack16_down_stem[i], D.cin, D.cout, D.cp, 0, e->stream)) return fail(-2, "pack launch failed");
         if (e->wpack16_up[i] && srt_launch_pack16(c + U.w, e->wpack16_up[i] + stem * e->wpack16_up_stem[i], U.cin, U.cout, U.cp, 1, e->stream)) return fail(-2, "pack launch failed");
+        if (e->wino_u[i] && srt_launch_pack_wino(c + U.w, e->wino_u[i] + stem * e->wino_u_stem[i], U.cin, U.cout, e->stream)) return fail(-2, "pack launch failed");
     }
     if (srt_launch_pack_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack2_u5 + (size_t)stem * 64 * 15 * 32, 64, 16, e->stream))
         return fail(-2, "pack launch failed");
@@ -444,6 +454,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 rc2 = srt_launch_dec_f16(p, e->stream);
             }
             if (e->act16 && i < 5 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for a decoder layer");
+            if (rc2 == 1 && e->wino_u[i] && (!small || srt_wino_force())) rc2 = srt_launch_dec_wino(p, e->wino_u[i] + (size_t)s0 * e->wino_u_stem[i], e->wino_u_stem[i], e->stream);
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_dec2(p, e->stream);
             if (rc2 < 0) return fail(-2, "decoder launch failed");
             if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");

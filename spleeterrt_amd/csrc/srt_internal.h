@@ -91,6 +91,12 @@ int  srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s);
 int  srt_set_sigmoid_table(const float* tbl1026);
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);
+// Winograd decoder kernels (srt_nn4.hip): U = transformed weights [Cin/4][Cout/16][4][16][52] per stem; the launcher returns 1
+// when the layer is not covered.  srt_wino_mask(): bit i set = up(i+1) runs this form (large batches, fp32 MFMA path).
+int  srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s);
+int  srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s);
+int  srt_wino_mask();
+int  srt_wino_force();
 
 // DSP launchers (srt_dsp.hip)
 struct SrtDspTables { const float* preWin; const float* postWin; const float2* twiddle; };

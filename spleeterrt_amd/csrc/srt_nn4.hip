@@ -1,0 +1,374 @@
+// srt_nn4.hip — Winograd form of the decoder's transposed convolutions (spleeter.c:239-294, 5x5 stride 2) on
+// v_mfma_f32_16x16x4_f32.
+//
+// A stride-2 transposed 5x5 convolution is four ordinary convolutions, one per output parity class (py, px): along an axis
+// the odd outputs see 3 taps (k = 4, 2, 0 at input shifts -1, 0, +1) and the even outputs 2 taps (k = 3, 1 at shifts -1, 0).
+// The direct kernels (srt_nn2.hip) spend 9 + 6 + 6 + 4 = 25 multiply-adds per input pixel, channel pair and output channel.
+// Winograd's minimal filtering over blocks of 2 x 2 input pixels (4 x 4 output pixels) needs F(2,3): 4 products per axis
+// for the 3-tap classes and F(2,2): 3 products for the 2-tap ones, i.e. 16 + 12 + 12 + 9 = 49 products per block against
+// 100: 2.04x fewer MFMA cycles.  With xi = 0..48 the transform point (class-major, then row-major inside the class):
+//
+//      M[xi][co][block] = sum over ci of  U[xi][ci][co] * V[xi][ci][block]            49 independent GEMMs, K = Cin
+//
+//   U = G_y g G_x^T   the transformed weights: computed ONCE per srtSetCoeff by srt_pack_wino_kernel (exact halves and sums
+//                     of the taps), stored [Cin/4][Cout/16][4][16][52] so that a workgroup's slab of a 4-channel K step is
+//                     13 KiB of contiguous memory, moved by 13 LDS-DMA instructions;
+//   V = B_y X B_x^T   the transformed 4 x 4 input patch (rows a0-1..a0+2, columns b0-1..b0+2) of the block: additions and
+//                     subtractions only, ~65 VALU instructions per thread and K step, written to LDS [ci][block][52];
+//   Y = A_y M A_x^T   the 2 x 2 outputs of the class, then bias -> activation -> batch-norm (spleeter.c:244-245).
+//
+// Workgroup = 16 output channels x 64 blocks; wave w owns blocks 16w..16w+15 and keeps all 49 accumulators of its
+// 16 x 16 tile (196 registers); a lane's k index is the input channel of the K step, so an A (B) fragment for four
+// consecutive xi is ONE ds_read_b128: 26 LDS reads feed the 49 MFMAs of a K step.  V and U are double buffered in LDS
+// (130 KB: one workgroup per CU, one wave per SIMD), so a K step has a single barrier: the next patch's global loads, its
+// transform and the next U slab's DMA are issued in the shadow of the current step's MFMAs.
+//
+// Numerics: U is exact up to one rounding per point (sums of at most 9 weights, scaled by 1/2 or 1/4); V and Y add one or two
+// roundings of additions.  The F(2,3)/F(2,2) matrices have entries 0, +-1, 1/2 only, so there is none of the cancellation
+// that larger Winograd tiles are known for; measured against the oracle the layer outputs agree to ~1e-6 relative.
+#include "srt_device.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WINO_LD 52                 // 49 points padded to 13 float4
+#define WINO_C11 0                 // class (py=1, px=1): 4 x 4 points
+#define WINO_C10 16                // class (1, 0): 4 x 3
+#define WINO_C01 28                // class (0, 1): 3 x 4
+#define WINO_C00 40                // class (0, 0): 3 x 3
+
+// ------------------------------------------------------------------------------------------- weight transform
+// 1-D: p = 1 taps (k = 4, 2, 0) -> [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2];  p = 0 taps (k = 3, 1) -> [g0, g0+g1, g1]
+__device__ __forceinline__ int wino_w1d(int p, const float* g, int stride, float* o)      // returns the number of points
+{
+    if (p) {
+        const float g0 = g[4 * stride], g1 = g[2 * stride], g2 = g[0];
+        o[0] = g0; o[1] = 0.5f * ((g0 + g2) + g1); o[2] = 0.5f * ((g0 + g2) - g1); o[3] = g2;
+        return 4;
+    }
+    const float g0 = g[3 * stride], g1 = g[stride];
+    o[0] = g0; o[1] = g0 + g1; o[2] = g1;
+    return 3;
+}
+__global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int ci = idx / Cout, co = idx % Cout;
+    const float* g = w + ((size_t)ci * Cout + co) * 25;                      // [ky][kx]
+    float out[WINO_LD];
+    int n = 0;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls < 2, px = !(cls & 1);                             // (1,1) (1,0) (0,1) (0,0)
+        float rowt[5][4];                                                    // x transform of each kernel row ky
+        int nx = 0;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) nx = wino_w1d(px, g + ky * 5, 1, rowt[ky]);
+        const int ny = py ? 4 : 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nx) continue;
+            float col[5], t[4];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) col[ky] = rowt[ky][j];
+            wino_w1d(py, col, 1, t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < ny) out[n + i * nx + j] = t[i];
+        }
+        n += ny * nx;
+    }
+    out[49] = out[50] = out[51] = 0.0f;
+    const int MB = Cout / 16;
+    float* dst = u + ((((size_t)(ci / 4) * MB + co / 16) * 4 + (ci & 3)) * 16 + (co & 15)) * WINO_LD;
+#pragma unroll
+    for (int q = 0; q < WINO_LD / 4; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+int srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s)
+{
+    if (Cin % 4 || Cout % 16) return -1;
+    hipLaunchKernelGGL(srt_pack_wino_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------- transforms (registers)
+// input: B3 = [d0-d2, d1+d2, d2-d1, d1-d3] (4 points), B2 = [d0-d1, d1, d1-d2] (3 points, d3 unused)
+__device__ __forceinline__ void wino_in3(float d0, float d1, float d2, float d3, float* o) { o[0] = d0 - d2; o[1] = d1 + d2; o[2] = d2 - d1; o[3] = d1 - d3; }
+// (the middle point is d1 itself; it gets its own register - an opaque v_mov - so that the loaded patch registers die with the row
+//  transforms and the next patch can be loaded straight into them: otherwise the value lives on as t2[r][1] until the last quad, the
+//  loads land elsewhere and a copy at the loop end waits for them)
+__device__ __forceinline__ void wino_in2(float d0, float d1, float d2, float* o)
+{
+    float c; asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(d1));
+    o[0] = d0 - d1; o[1] = c; o[2] = d1 - d2;
+}
+// output: A3: y0 = m0+m1+m2, y1 = m1-m2-m3;  A2: y0 = m0+m1, y1 = m1-m2
+template <int N> __device__ __forceinline__ void wino_out1d(const float* m, int stride, float& y0, float& y1)
+{
+    if (N == 4) { y0 = (m[0] + m[stride]) + m[2 * stride]; y1 = (m[stride] - m[2 * stride]) - m[3 * stride]; }
+    else { y0 = m[0] + m[stride]; y1 = m[stride] - m[2 * stride]; }
+}
+template <int NY, int NX> __device__ __forceinline__ void wino_out2d(const float* m, float (&y)[2][2])      // m[NY][NX]
+{
+    float z[4][2];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) wino_out1d<NX>(m + i * NX, 1, z[i][0], z[i][1]);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float c[4] = { z[0][d], z[1][d], z[2][d], NY == 4 ? z[3][d] : 0.0f };
+        wino_out1d<NY>(c, 1, y[0][d], y[1][d]);
+    }
+}
+
+// transform point X (compile-time) of the next K step from the row-transformed patch: class-major, then [i][j] inside the class
+template <int X> __device__ __forceinline__ float wino_point(const float (&t3)[4][4], const float (&t2)[4][3])
+{
+    constexpr int cls = X < WINO_C10 ? 0 : X < WINO_C01 ? 1 : X < WINO_C00 ? 2 : 3;
+    constexpr int e = X - (cls == 0 ? WINO_C11 : cls == 1 ? WINO_C10 : cls == 2 ? WINO_C01 : WINO_C00);
+    constexpr bool y3 = cls < 2, x3 = !(cls & 1);                            // 3-tap (4-point) transform along y / x
+    constexpr int nx = x3 ? 4 : 3, i = e / nx, j = e % nx;
+    float c0, c1, c2, c3;
+    if constexpr (x3) { c0 = t3[0][j]; c1 = t3[1][j]; c2 = t3[2][j]; c3 = t3[3][j]; }
+    else { c0 = t2[0][j]; c1 = t2[1][j]; c2 = t2[2][j]; c3 = t2[3][j]; }
+    if constexpr (y3) return i == 0 ? c0 - c2 : i == 1 ? c1 + c2 : i == 2 ? c2 - c1 : c1 - c3;
+    else return i == 0 ? c0 - c1 : i == 1 ? c1 : c1 - c2;
+}
+template <int I, int N> struct WinoFor {                                    // compile-time loop: f(integral_constant<I>) ... f(integral_constant<N-1>)
+    template <class F> static __device__ __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); WinoFor<I + 1, N>::run(f); }
+};
+template <int N> struct WinoFor<N, N> { template <class F> static __device__ __forceinline__ void run(F&&) {} };
+
+// ------------------------------------------------------------------------------------------- the layer kernel
+// tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BB % 16 == 0 or (BA*BB) % 16 == 0.
+// Requires H, W even, Cin % 8 == 0, CA % 4 == 0, Cout % 16 == 0 (the launcher checks).
+//
+// Lane (kq = lane / 16, l15 = lane % 16) of wave w owns block 16 w + l15 and, in K step k, input channel 4 k + kq: exactly the
+// (k, n) element the 16x16x4 MFMA wants from this lane as its B operand.  So the lane loads that block's 4 x 4 patch of that
+// channel itself (12 buffer loads; rows/columns outside the image get an out-of-range offset and come back as 0.0), transforms
+// it in registers, and the 49 results ARE its B operands of the K step: V never touches LDS.  Only U (shared by the four waves)
+// goes through LDS, by DMA, double buffered: one barrier per K step.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int BA, int BB, int NI>
+__global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
+{
+    static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
+    constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
+    __shared__ __attribute__((aligned(16))) float s_u[2 * UBUF];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int TH = 2 * BA, TW = 2 * BB;
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
+    const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, MB, p.nstems, groups);
+    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
+    const int m0 = bc.mblk * 16, stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const float* up = U + stem * u_stem + (size_t)bc.mblk * UBUF;            // K step k at + k * MB * UBUF
+
+    const int blk = wave * 16 + l15;
+    const int il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
+    const int a0 = ty0 + 2 * ba, b0 = tx0 + 2 * bb, tile = tile0 + il;
+    const bool blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
+
+    // byte offsets of the patch from (channel 4k of instance tile0): [row][left column b0-1, pair (b0, b0+1), right column b0+2]
+    constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: the buffer load returns 0
+    unsigned voff[4][3];
+    {
+        const unsigned inst = 4u * (unsigned)((size_t)il * p.srcA_tile + (size_t)kq * hw);      // srcA_tile == srcB_tile (launcher)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = a0 - 1 + r;
+            const bool rok = blk_ok && gy >= 0 && gy < p.H;
+            const unsigned o = inst + 4u * (unsigned)(gy * p.W + b0);
+            voff[r][0] = (rok && b0 - 1 >= 0) ? o - 4u : OOR;
+            voff[r][1] = rok ? o : OOR;
+            voff[r][2] = (rok && b0 + 2 < p.W) ? o + 8u : OOR;
+        }
+    }
+    const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
+    const float* pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;     // wave-uniform
+    const float* pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
+    const int kA = p.CA / 4;                                                 // K steps [0, kA) read srcA, the rest srcB (CA % 4 == 0)
+    const unsigned kstep_bytes = (unsigned)(16 * hw);                        // 4 channels
+    float xl[4], xr[4]; u32x2 xm[4];                                         // patch row r: columns b0-1 | (b0, b0+1) as loaded (one 64-bit register) | b0+2
+    struct PatchSrc { __amdgpu_buffer_rsrc_t rs; unsigned soff; };
+    auto patch_src = [&](int k) {                                            // K-step uniform: a few SALU instructions
+        PatchSrc ps;
+        const bool fromA = k < kA;
+        ps.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fromA ? pa : pb), 0, nrec, 0x00020000);
+        ps.soff = (unsigned)(fromA ? k : k - kA) * kstep_bytes;
+        return ps;
+    };
+    auto load_row = [&](const PatchSrc& ps, int r) {                         // 3 loads: columns b0-1 | b0, b0+1 | b0+2 of patch row r
+        xl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voff[r][0], ps.soff, 0));
+        xm[r] = __builtin_amdgcn_raw_buffer_load_b64(ps.rs, voff[r][1], ps.soff, 0);
+        xr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voff[r][2], ps.soff, 0));
+    };
+    // the transform in two stages: rows (x direction) of the loaded patch -> t3 / t2, then one transform point at a time
+    float t3[4][4], t2[4][3];
+    auto rows3 = [&](int r) { wino_in3(xl[r], __uint_as_float(xm[r].x), __uint_as_float(xm[r].y), xr[r], t3[r]); };
+    auto rows2 = [&](int r) { wino_in2(xl[r], __uint_as_float(xm[r].x), __uint_as_float(xm[r].y), t2[r]); };
+    // U slab k -> LDS buffer `buf`: 13 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, min(w+12, 12) (three waves repeat piece 12:
+    // same bytes, and no branch).  The DMA is issued from inline assembly on purpose: the compiler's bookkeeping of LDS-DMA
+    // (__builtin_amdgcn_global_load_lds) makes every later LDS read wait for vmcnt(0) - here that would be the DMA of the NEXT
+    // slab and the patch loads issued just before the operand reads (measured: 2.8x the MFMA time per K step).  Arrival is
+    // synchronised by hand instead: an s_waitcnt vmcnt in front of the K step's barrier.  (m0 is not used by anything else here.)
+    const unsigned lds_u = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_u;
+    unsigned dvoff[4], dm0[4];                                               // per piece: byte offset inside the slab (+ lane*16), LDS byte address in buffer 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = min(wave + 4 * i, 12);
+        dvoff[i] = (unsigned)(piece * 1024 + lane * 16);
+        dm0[i] = __builtin_amdgcn_readfirstlane(lds_u + (unsigned)(piece * 1024));
+    }
+    auto dma_piece = [&](int k, int buf, int i) {
+        const float* src = up + (size_t)k * MB * UBUF;                       // wave-uniform: SGPR base + VGPR offset
+        const unsigned dst = dm0[i] + (unsigned)buf * (unsigned)(UBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
+    };
+
+    f32x4 acc[49];
+#pragma unroll
+    for (int x = 0; x < 49; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
+
+    // epilogue constants before the K loop (see srt_dec16_kernel)
+    float bi[4], sc[4], sf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t ci = stem * p.coeff_stem + m0 + 4 * kq + r;
+        bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+    }
+
+    const int nk = p.Cin / 4;
+    const int aoff = (kq * 16 + l15) * WINO_LD;
+    // K step k, in MFMA quads q = 0..12 (4 transform points each, 1 for the last).  Quad q issues its 4 MFMAs on v[4q..4q+3], the
+    // points of THIS step, and then refills those registers with the points of step k+1, computed from the row transforms t3 / t2 of
+    // patch k+1 (in xl/xm/xr since the previous step).  Everything else a step needs rides in the issue slots between those MFMAs (one wave
+    // per SIMD: about five other instructions fit beside a 32-cycle MFMA), spread by hand and pinned with sched_barrier:
+    //   quads 0-3   one DMA piece of U slab k+1 each; the row transforms (t3 rows as the class-(1,1) points first need them, t2 rows
+    //               in between); after quad 3 the patch registers are dead
+    //   quads 4-7   the three loads of one row of patch k+2 each (5 quads + the barrier ahead of their first use)
+    //   all quads   the A operand read of quad q+2
+    float v[49];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(0, 0, i);
+    {
+        const PatchSrc ps = patch_src(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_row(ps, r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rows3(r); rows2(r); }
+        WinoFor<0, 49>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<x>(t3, t2); });
+        const PatchSrc p1 = patch_src(min(1, nk - 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_row(p1, r);
+    }
+    for (int k = 0; k < nk; ++k) {
+        // vmcnt(12): everything older than the 12 loads of patch k+1 has landed - in particular this wave's DMA pieces of slab k.
+        // After the barrier so have everyone's, and every wave is done reading the other buffer.
+        __builtin_amdgcn_s_waitcnt(0x0F7C);
+        __syncthreads();
+        const int buf = k & 1, kd = min(k + 1, nk - 1);                      // (the last step refills the free buffer with its own slab
+        const PatchSrc ps = patch_src(min(k + 2, nk - 1));                   //  and re-reads its own patch: both unused)
+        const float* ub = s_u + buf * UBUF + aoff;
+        float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        WinoFor<0, 13>::run([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const float4 a = a0;
+            a0 = a1;
+            if constexpr (q < 11) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
+            if constexpr (q == 0) { rows3(0); rows3(2); __builtin_amdgcn_sched_barrier(0); }     // (the compiler waits for vmcnt(0) here: before the first DMA piece)
+            if constexpr (q < 4) dma_piece(kd, buf ^ 1, q);
+            if constexpr (q == 1) { rows3(1); rows2(0); }
+            if constexpr (q == 2) { rows2(1); rows2(2); }
+            if constexpr (q == 3) { rows3(3); rows2(3); }                    // the patch registers are dead from here on
+            if constexpr (q >= 4 && q <= 7) load_row(ps, q - 4);
+            acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
+            v[4 * q] = wino_point<4 * q>(t3, t2);
+            if constexpr (q < 12) {
+                acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
+                v[4 * q + 1] = wino_point<4 * q + 1>(t3, t2);
+                acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
+                v[4 * q + 2] = wino_point<4 * q + 2>(t3, t2);
+                acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
+                v[4 * q + 3] = wino_point<4 * q + 3>(t3, t2);
+            }
+            __builtin_amdgcn_sched_barrier(0);                               // quads stay in order: bounded live ranges, no accumulator copies
+        });
+    }
+
+    // ---- output transform + bias -> activation -> batch-norm; lane = block (wave*16 + l15), channels m0 + 4*kq + r
+    if (!blk_ok) return;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float* o = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(2 * a0) * Wo + 2 * b0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m[49];
+#pragma unroll
+        for (int x = 0; x < 49; ++x) m[x] = acc[x][r];
+        float y11[2][2], y10[2][2], y01[2][2], y00[2][2];
+        wino_out2d<4, 4>(m + WINO_C11, y11);
+        wino_out2d<4, 3>(m + WINO_C10, y10);
+        wino_out2d<3, 4>(m + WINO_C01, y01);
+        wino_out2d<3, 3>(m + WINO_C00, y00);
+        float* oc = o + (size_t)(m0 + 4 * kq + r) * ohw;
+#pragma unroll
+        for (int da = 0; da < 2; ++da) {
+            // output rows 2(a0+da)+py, columns 2(b0+db)+px: one float4 = (px0 db0, px1 db0, px0 db1, px1 db1)
+            float4 e0, e1;
+            e0.x = srt_dec_epilogue(y00[da][0], bi[r], sc[r], sf[r], actp); e0.y = srt_dec_epilogue(y01[da][0], bi[r], sc[r], sf[r], actp);
+            e0.z = srt_dec_epilogue(y00[da][1], bi[r], sc[r], sf[r], actp); e0.w = srt_dec_epilogue(y01[da][1], bi[r], sc[r], sf[r], actp);
+            e1.x = srt_dec_epilogue(y10[da][0], bi[r], sc[r], sf[r], actp); e1.y = srt_dec_epilogue(y11[da][0], bi[r], sc[r], sf[r], actp);
+            e1.z = srt_dec_epilogue(y10[da][1], bi[r], sc[r], sf[r], actp); e1.w = srt_dec_epilogue(y11[da][1], bi[r], sc[r], sf[r], actp);
+            *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e0;          // py = 0
+            *reinterpret_cast<float4*>(oc + (size_t)(2 * da + 1) * Wo) = e1;      // py = 1
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- launcher
+// Which decoder layers (bit i = up(i+1)) run this form.  The default is the set measured faster than the direct kernels on
+// MI355X at 64 tiles x 4 stems; a -DSRT_TUNING build overrides it with SRT_TUNE=wino=<mask>.
+#ifndef SRT_WINO_DEFAULT_MASK
+#define SRT_WINO_DEFAULT_MASK 0
+#endif
+int srt_wino_mask()
+{
+#ifdef SRT_TUNING
+    const char* e = getenv("SRT_TUNE");
+    const char* q = e ? strstr(e, "wino=") : nullptr;
+    if (q && (q == e || q[-1] == ',')) return atoi(q + 5);
+#endif
+    return SRT_WINO_DEFAULT_MASK;
+}
+int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 runs this form for small batches too (parity tests at oracle sizes)
+{
+#ifdef SRT_TUNING
+    const char* e = getenv("SRT_TUNE");
+    const char* q = e ? strstr(e, "winoforce=") : nullptr;
+    if (q) return atoi(q + 10);
+#endif
+    return 0;
+}
+int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
+{
+    if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 1)) return 1;
+    const int MB = p.Cout / 16;
+    if (p.H >= 8 && p.W >= 32) {
+        const long wgs = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * MB * p.nstems * p.ntiles;
+        if (wgs < 256 && !srt_wino_force()) return 1;                        // small batches: the split-K direct kernels
+        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem);
+    } else if (p.H >= 4 && p.W >= 16) {
+        const long wgs = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * MB * p.nstems * ((p.ntiles + 3) / 4);
+        if (wgs < 256 && !srt_wino_force()) return 1;
+        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem);
+    } else return 1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
