@@ -150,7 +150,7 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // it in registers, and the 49 results ARE its B operands of the K step: V never touches LDS.  Only U (shared by the four waves)
 // goes through LDS, by DMA, double buffered: one barrier per K step.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <int BA, int BB, int NI>
+template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch loads, 3 no DMA, 4 no transform, 5 no A reads
 __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
@@ -173,9 +173,15 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     const int a0 = ty0 + 2 * ba, b0 = tx0 + 2 * bb, tile = tile0 + il;
     const bool blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
 
-    // byte offsets of the patch from (channel 4k of instance tile0): [row][left column b0-1, pair (b0, b0+1), right column b0+2]
+    // byte offsets of the patch from (channel 4k of instance tile0).  Per patch row a lane loads its own column pair (b0, b0+1) -
+    // 16 lanes x 8 B contiguous per channel - and gets the two outer columns from its neighbours' pairs by DPP (the 16 lanes of a DPP
+    // row are the blocks of one tile row, or of two for BB = 8): b0-1 is the left neighbour's second column, b0+2 the right neighbour's
+    // first.  Only the blocks at the ends of a tile row have no such neighbour: they fetch that one column with a second, single-dword
+    // load whose offset is out of range for every other lane (measured: with three loads per row and lane - the outer columns as
+    // stride-2 dword loads - the patch loads were 28 % of the layer time).
     constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: the buffer load returns 0
-    unsigned voff[4][3];
+    const bool edgeL = bb == 0, edgeR = bb == BB - 1;
+    unsigned voffm[4], voffe[4];
     {
         const unsigned inst = 4u * (unsigned)((size_t)il * p.srcA_tile + (size_t)kq * hw);      // srcA_tile == srcB_tile (launcher)
 #pragma unroll
@@ -183,9 +189,8 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
             const int gy = a0 - 1 + r;
             const bool rok = blk_ok && gy >= 0 && gy < p.H;
             const unsigned o = inst + 4u * (unsigned)(gy * p.W + b0);
-            voff[r][0] = (rok && b0 - 1 >= 0) ? o - 4u : OOR;
-            voff[r][1] = rok ? o : OOR;
-            voff[r][2] = (rok && b0 + 2 < p.W) ? o + 8u : OOR;
+            voffm[r] = rok ? o : OOR;
+            voffe[r] = (rok && edgeL && b0 - 1 >= 0) ? o - 4u : (rok && edgeR && b0 + 2 < p.W) ? o + 8u : OOR;
         }
     }
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     const float* pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
     const int kA = p.CA / 4;                                                 // K steps [0, kA) read srcA, the rest srcB (CA % 4 == 0)
     const unsigned kstep_bytes = (unsigned)(16 * hw);                        // 4 channels
-    float xl[4], xr[4]; u32x2 xm[4];                                         // patch row r: columns b0-1 | (b0, b0+1) as loaded (one 64-bit register) | b0+2
+    float xe[4]; u32x2 xm[4];                                                // patch row r: the edge column (tile-row ends only) | columns (b0, b0+1), one 64-bit register
     struct PatchSrc { __amdgpu_buffer_rsrc_t rs; unsigned soff; };
     auto patch_src = [&](int k) {                                            // K-step uniform: a few SALU instructions
         PatchSrc ps;
@@ -202,15 +207,22 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
         ps.soff = (unsigned)(fromA ? k : k - kA) * kstep_bytes;
         return ps;
     };
-    auto load_row = [&](const PatchSrc& ps, int r) {                         // 3 loads: columns b0-1 | b0, b0+1 | b0+2 of patch row r
-        xl[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voff[r][0], ps.soff, 0));
-        xm[r] = __builtin_amdgcn_raw_buffer_load_b64(ps.rs, voff[r][1], ps.soff, 0);
-        xr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voff[r][2], ps.soff, 0));
+    auto load_row = [&](const PatchSrc& ps, int r) {
+        xm[r] = __builtin_amdgcn_raw_buffer_load_b64(ps.rs, voffm[r], ps.soff, 0);
+        xe[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voffe[r], ps.soff, 0));
     };
     // the transform in two stages: rows (x direction) of the loaded patch -> t3 / t2, then one transform point at a time
     float t3[4][4], t2[4][3];
-    auto rows3 = [&](int r) { wino_in3(xl[r], __uint_as_float(xm[r].x), __uint_as_float(xm[r].y), xr[r], t3[r]); };
-    auto rows2 = [&](int r) { wino_in2(xl[r], __uint_as_float(xm[r].x), __uint_as_float(xm[r].y), t2[r]); };
+    auto rows = [&](int r, bool want3, bool want2) {
+        const int e = __float_as_int(xe[r]);
+        // row_shr:1 / row_shl:1 inside the 16-lane DPP row; a lane without a source keeps `old` (= its edge column)
+        int l = __builtin_amdgcn_update_dpp(e, (int)xm[r].y, 0x111, 0xf, 0xf, false);
+        int q = __builtin_amdgcn_update_dpp(e, (int)xm[r].x, 0x101, 0xf, 0xf, false);
+        if (BB != 16) { l = edgeL ? e : l; q = edgeR ? e : q; }               // tile rows shorter than a DPP row
+        const float d0 = __int_as_float(l), d1 = __uint_as_float(xm[r].x), d2 = __uint_as_float(xm[r].y), d3 = __int_as_float(q);
+        if (want3) wino_in3(d0, d1, d2, d3, t3[r]);
+        if (want2) wino_in2(d0, d1, d2, t2[r]);
+    };
     // U slab k -> LDS buffer `buf`: 13 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, min(w+12, 12) (three waves repeat piece 12:
     // same bytes, and no branch).  The DMA is issued from inline assembly on purpose: the compiler's bookkeeping of LDS-DMA
     // (__builtin_amdgcn_global_load_lds) makes every later LDS read wait for vmcnt(0) - here that would be the DMA of the NEXT
@@ -252,7 +264,7 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     // per SIMD: about five other instructions fit beside a 32-cycle MFMA), spread by hand and pinned with sched_barrier:
     //   quads 0-3   one DMA piece of U slab k+1 each; the row transforms (t3 rows as the class-(1,1) points first need them, t2 rows
     //               in between); after quad 3 the patch registers are dead
-    //   quads 4-7   the three loads of one row of patch k+2 each (5 quads + the barrier ahead of their first use)
+    //   quads 4-7   the two loads of one row of patch k+2 each (5 quads + the barrier ahead of their first use)
     //   all quads   the A operand read of quad q+2
     float v[49];
 #pragma unroll
@@ -262,17 +274,16 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_row(ps, r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { rows3(r); rows2(r); }
+        for (int r = 0; r < 4; ++r) rows(r, true, true);
         WinoFor<0, 49>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<x>(t3, t2); });
         const PatchSrc p1 = patch_src(min(1, nk - 1));
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_row(p1, r);
     }
     for (int k = 0; k < nk; ++k) {
-        // vmcnt(12): everything older than the 12 loads of patch k+1 has landed - in particular this wave's DMA pieces of slab k.
+        // vmcnt(8): everything older than the 8 loads of patch k+1 has landed - in particular this wave's DMA pieces of slab k.
         // After the barrier so have everyone's, and every wave is done reading the other buffer.
-        __builtin_amdgcn_s_waitcnt(0x0F7C);
-        __syncthreads();
+        if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F78); __syncthreads(); }
         const int buf = k & 1, kd = min(k + 1, nk - 1);                      // (the last step refills the free buffer with its own slab
         const PatchSrc ps = patch_src(min(k + 2, nk - 1));                   //  and re-reads its own patch: both unused)
         const float* ub = s_u + buf * UBUF + aoff;
@@ -282,22 +293,21 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
             constexpr int q = decltype(qc)::value;
             const float4 a = a0;
             a0 = a1;
-            if constexpr (q < 11) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
-            if constexpr (q == 0) { rows3(0); rows3(2); __builtin_amdgcn_sched_barrier(0); }     // (the compiler waits for vmcnt(0) here: before the first DMA piece)
-            if constexpr (q < 4) dma_piece(kd, buf ^ 1, q);
-            if constexpr (q == 1) { rows3(1); rows2(0); }
-            if constexpr (q == 2) { rows2(1); rows2(2); }
-            if constexpr (q == 3) { rows3(3); rows2(3); }                    // the patch registers are dead from here on
-            if constexpr (q >= 4 && q <= 7) load_row(ps, q - 4);
+            if constexpr (q < 11 && ABL != 5) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
+            if constexpr (q == 0 && ABL != 4) { rows(0, true, true); rows(2, true, true); __builtin_amdgcn_sched_barrier(0); }     // (the compiler waits for vmcnt(0) here: before the first DMA piece)
+            if constexpr (q < 4 && ABL != 3) dma_piece(kd, buf ^ 1, q);
+            if constexpr (q == 1 && ABL != 4) { rows(1, true, true); }
+            if constexpr (q == 3 && ABL != 4) { rows(3, true, true); }                    // the patch registers are dead from here on
+            if constexpr (q >= 4 && q <= 7 && ABL != 2) load_row(ps, q - 4);
             acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
-            v[4 * q] = wino_point<4 * q>(t3, t2);
+            if constexpr (ABL != 4) v[4 * q] = wino_point<4 * q>(t3, t2);
             if constexpr (q < 12) {
                 acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
-                v[4 * q + 1] = wino_point<4 * q + 1>(t3, t2);
+                if constexpr (ABL != 4) v[4 * q + 1] = wino_point<4 * q + 1>(t3, t2);
                 acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
-                v[4 * q + 2] = wino_point<4 * q + 2>(t3, t2);
+                if constexpr (ABL != 4) v[4 * q + 2] = wino_point<4 * q + 2>(t3, t2);
                 acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
-                v[4 * q + 3] = wino_point<4 * q + 3>(t3, t2);
+                if constexpr (ABL != 4) v[4 * q + 3] = wino_point<4 * q + 3>(t3, t2);
             }
             __builtin_amdgcn_sched_barrier(0);                               // quads stay in order: bounded live ranges, no accumulator copies
         });
@@ -339,23 +349,29 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
 #ifndef SRT_WINO_DEFAULT_MASK
 #define SRT_WINO_DEFAULT_MASK 0
 #endif
+#ifdef SRT_TUNING
+static int wino_tune(const char* key)                                        // key includes the '='
+{
+    const char* e = getenv("SRT_TUNE");
+    const char* q = e ? strstr(e, key) : nullptr;
+    return (q && (q == e || q[-1] == ',')) ? atoi(q + strlen(key)) : -1;
+}
+#endif
 int srt_wino_mask()
 {
 #ifdef SRT_TUNING
-    const char* e = getenv("SRT_TUNE");
-    const char* q = e ? strstr(e, "wino=") : nullptr;
-    if (q && (q == e || q[-1] == ',')) return atoi(q + 5);
+    const int m = wino_tune("wino=");
+    if (m >= 0) return m;
 #endif
     return SRT_WINO_DEFAULT_MASK;
 }
 int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 runs this form for small batches too (parity tests at oracle sizes)
 {
 #ifdef SRT_TUNING
-    const char* e = getenv("SRT_TUNE");
-    const char* q = e ? strstr(e, "winoforce=") : nullptr;
-    if (q) return atoi(q + 10);
-#endif
+    return wino_tune("winoforce=") > 0;
+#else
     return 0;
+#endif
 }
 int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
 {
@@ -364,6 +380,15 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
     if (p.H >= 8 && p.W >= 32) {
         const long wgs = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * MB * p.nstems * p.ntiles;
         if (wgs < 256 && !srt_wino_force()) return 1;                        // small batches: the split-K direct kernels
+#ifdef SRT_TUNING
+        switch (wino_tune("winoabl=")) {
+        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        }
+#endif
         hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem);
     } else if (p.H >= 4 && p.W >= 16) {
         const long wgs = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * MB * p.nstems * ((p.ntiles + 3) / 4);
