@@ -141,24 +141,40 @@ template <int I, int N> struct WinoFor {                                    // c
 template <int N> struct WinoFor<N, N> { template <class F> static __device__ __forceinline__ void run(F&&) {} };
 
 // ------------------------------------------------------------------------------------------- the layer kernel
-// tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BB % 16 == 0 or (BA*BB) % 16 == 0.
-// Requires H, W even, Cin % 8 == 0, CA % 4 == 0, Cout % 16 == 0 (the launcher checks).
+// tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BA * BB == 16 * (waves per instance).
+// Requires H even, W % 4 == 0, Cin % 4 == 0, CA % 4 == 0, Cout % 16 == 0 (the launcher checks).
 //
 // Lane (kq = lane / 16, l15 = lane % 16) of wave w owns block 16 w + l15 and, in K step k, input channel 4 k + kq: exactly the
-// (k, n) element the 16x16x4 MFMA wants from this lane as its B operand.  So the lane loads that block's 4 x 4 patch of that
-// channel itself (12 buffer loads; rows/columns outside the image get an out-of-range offset and come back as 0.0), transforms
-// it in registers, and the 49 results ARE its B operands of the K step: V never touches LDS.  Only U (shared by the four waves)
-// goes through LDS, by DMA, double buffered: one barrier per K step.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch loads, 3 no DMA, 4 no transform, 5 no A reads
+// (k, n) element the 16x16x4 MFMA wants from this lane as its B operand.  So the lane transforms that block's 4 x 4 patch of that
+// channel itself, in registers, and the 49 results ARE its B operands of the K step: V never touches LDS.
+//
+// Global memory reaches the CU by LDS-DMA only (no load has a register destination, so nothing in flight pins registers and the
+// prefetch distance is free to choose):
+//   U slab k+1   13 pieces of 1 KiB (global_load_lds), two buffers: lands one step ahead; weights come from the XCD's L2
+//   patch k+3    the tile's 4-channel input patch, rows ty0-1..ty0+TH, columns tx0-4..tx0+TW+3 as aligned float4s
+//                (buffer_load_dwordx4 ... lds: a float4 outside the image has an out-of-range offset and lands as zeros), three
+//                buffers: lands TWO steps ahead, because each XCD walks its own (stem, M-block) slice of the launch (weights stay
+//                in its L2) and therefore every patch is an L2 miss.  (Measured with register-destination loads issued half a
+//                step ahead: the K step waited on them for 28 % of the layer time.)
+// All DMA is issued from inline assembly: the compiler's own bookkeeping of LDS-DMA makes every later LDS read wait for vmcnt(0),
+// i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
 __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
-    __shared__ __attribute__((aligned(16))) float s_u[2 * UBUF];
+    constexpr int TH = 2 * BA, TW = 2 * BB;
+    constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;                // patch: PH rows of PROW floats per (channel, instance)
+    constexpr int PCH = NI * PH * PROW;                                      // floats per channel
+    constexpr int NF4 = 4 * PCH / 4, NPP = (NF4 + 63) / 64, PBUF = NPP * 256; // float4s, DMA pieces and floats per patch buffer
+    constexpr int PPW = (NPP + 3) / 4;                                       // pieces per wave
+    __shared__ __attribute__((aligned(16))) float s_all[2 * UBUF + 3 * PBUF];
+    float* s_u = s_all;
+    float* s_p = s_all + 2 * UBUF;
+
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int TH = 2 * BA, TW = 2 * BB;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
     const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, MB, p.nstems, groups);
@@ -172,74 +188,60 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     const int il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
     const int a0 = ty0 + 2 * ba, b0 = tx0 + 2 * bb, tile = tile0 + il;
     const bool blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
 
-    // byte offsets of the patch from (channel 4k of instance tile0).  Per patch row a lane loads its own column pair (b0, b0+1) -
-    // 16 lanes x 8 B contiguous per channel - and gets the two outer columns from its neighbours' pairs by DPP (the 16 lanes of a DPP
-    // row are the blocks of one tile row, or of two for BB = 8): b0-1 is the left neighbour's second column, b0+2 the right neighbour's
-    // first.  Only the blocks at the ends of a tile row have no such neighbour: they fetch that one column with a second, single-dword
-    // load whose offset is out of range for every other lane (measured: with three loads per row and lane - the outer columns as
-    // stride-2 dword loads - the patch loads were 28 % of the layer time).
-    constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: the buffer load returns 0
-    const bool edgeL = bb == 0, edgeR = bb == BB - 1;
-    unsigned voffm[4], voffe[4];
-    {
-        const unsigned inst = 4u * (unsigned)((size_t)il * p.srcA_tile + (size_t)kq * hw);      // srcA_tile == srcB_tile (launcher)
+    // ---- U slab DMA: wave w moves pieces w, w+4, w+8, min(w+12, 12) (three waves repeat piece 12: same bytes, and no branch)
+    unsigned dvoff[4], dm0[4];                                               // byte offset inside the slab (+ lane*16), LDS byte address in buffer 0
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = a0 - 1 + r;
-            const bool rok = blk_ok && gy >= 0 && gy < p.H;
-            const unsigned o = inst + 4u * (unsigned)(gy * p.W + b0);
-            voffm[r] = rok ? o : OOR;
-            voffe[r] = (rok && edgeL && b0 - 1 >= 0) ? o - 4u : (rok && edgeR && b0 + 2 < p.W) ? o + 8u : OOR;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int piece = min(wave + 4 * i, 12);
+        dvoff[i] = (unsigned)(piece * 1024 + lane * 16);
+        dm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(piece * 1024));
+    }
+    auto dma_u = [&](int k, int buf, int i) {
+        const float* src = up + (size_t)k * MB * UBUF;                       // wave-uniform: SGPR base + VGPR offset
+        const unsigned dst = dm0[i] + (unsigned)buf * (unsigned)(UBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
+    };
+    // ---- patch DMA: float4 e = ((c * NI + il) * PH + row) * PR4 + j of the patch buffer <- channel 4k+c, instance tile0+il,
+    // image row ty0-1+row, columns tx0-4+4j..+3.  Wave w moves pieces w, w+4, ... (a piece past the last one repeats it).
+    constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: lands as zeros
+    unsigned pvoff[PPW], pm0[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = min(wave + 4 * i, NPP - 1), e = piece * 64 + lane;
+        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+        const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
+        const bool ok = e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        pvoff[i] = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;      // srcA_tile == srcB_tile (launcher)
+        pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * UBUF * 4 + piece * 1024));
     }
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
     const float* pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;     // wave-uniform
     const float* pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
     const int kA = p.CA / 4;                                                 // K steps [0, kA) read srcA, the rest srcB (CA % 4 == 0)
     const unsigned kstep_bytes = (unsigned)(16 * hw);                        // 4 channels
-    float xe[4]; u32x2 xm[4];                                                // patch row r: the edge column (tile-row ends only) | columns (b0, b0+1), one 64-bit register
-    struct PatchSrc { __amdgpu_buffer_rsrc_t rs; unsigned soff; };
-    auto patch_src = [&](int k) {                                            // K-step uniform: a few SALU instructions
-        PatchSrc ps;
+    auto dma_patch = [&](int k, int slot, int i) {
         const bool fromA = k < kA;
-        ps.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fromA ? pa : pb), 0, nrec, 0x00020000);
-        ps.soff = (unsigned)(fromA ? k : k - kA) * kstep_bytes;
-        return ps;
+        const size_t base = (size_t)(fromA ? pa : pb);
+        i32x4 rs;
+        rs.x = (int)(unsigned)(base & 0xffffffffu); rs.y = (int)(unsigned)((base >> 32) & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
+        const unsigned soff = (unsigned)(fromA ? k : k - kA) * kstep_bytes;
+        const unsigned dst = pm0[i] + (unsigned)slot * (unsigned)(PBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(pvoff[i]), "s"(rs), "s"(dst), "s"(soff) : "memory");
     };
-    auto load_row = [&](const PatchSrc& ps, int r) {
-        xm[r] = __builtin_amdgcn_raw_buffer_load_b64(ps.rs, voffm[r], ps.soff, 0);
-        xe[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ps.rs, voffe[r], ps.soff, 0));
-    };
-    // the transform in two stages: rows (x direction) of the loaded patch -> t3 / t2, then one transform point at a time
+    // ---- the transform in two stages: rows (x direction) of the patch -> t3 / t2, then one transform point at a time
+    const int poff = ((kq * NI + il) * PH + 2 * ba) * PROW + 2 * bb + 3;     // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
     float t3[4][4], t2[4][3];
-    auto rows = [&](int r, bool want3, bool want2) {
-        const int e = __float_as_int(xe[r]);
-        // row_shr:1 / row_shl:1 inside the 16-lane DPP row; a lane without a source keeps `old` (= its edge column)
-        int l = __builtin_amdgcn_update_dpp(e, (int)xm[r].y, 0x111, 0xf, 0xf, false);
-        int q = __builtin_amdgcn_update_dpp(e, (int)xm[r].x, 0x101, 0xf, 0xf, false);
-        if (BB != 16) { l = edgeL ? e : l; q = edgeR ? e : q; }               // tile rows shorter than a DPP row
-        const float d0 = __int_as_float(l), d1 = __uint_as_float(xm[r].x), d2 = __uint_as_float(xm[r].y), d3 = __int_as_float(q);
-        if (want3) wino_in3(d0, d1, d2, d3, t3[r]);
-        if (want2) wino_in2(d0, d1, d2, t2[r]);
+    float2 xm[4], xo[4];                                                     // patch row r: columns (b0, b0+1) | (b0-1, b0+2)
+    auto read_row = [&](const float* pbuf, int r) {
+        const float* q = pbuf + poff + r * PROW;
+        xm[r] = *reinterpret_cast<const float2*>(q + 1);                     // 8-byte aligned (2 bb + 4)
+        xo[r] = make_float2(q[0], q[3]);                                     // one ds_read2_b32
     };
-    // U slab k -> LDS buffer `buf`: 13 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, min(w+12, 12) (three waves repeat piece 12:
-    // same bytes, and no branch).  The DMA is issued from inline assembly on purpose: the compiler's bookkeeping of LDS-DMA
-    // (__builtin_amdgcn_global_load_lds) makes every later LDS read wait for vmcnt(0) - here that would be the DMA of the NEXT
-    // slab and the patch loads issued just before the operand reads (measured: 2.8x the MFMA time per K step).  Arrival is
-    // synchronised by hand instead: an s_waitcnt vmcnt in front of the K step's barrier.  (m0 is not used by anything else here.)
-    const unsigned lds_u = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_u;
-    unsigned dvoff[4], dm0[4];                                               // per piece: byte offset inside the slab (+ lane*16), LDS byte address in buffer 0
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = min(wave + 4 * i, 12);
-        dvoff[i] = (unsigned)(piece * 1024 + lane * 16);
-        dm0[i] = __builtin_amdgcn_readfirstlane(lds_u + (unsigned)(piece * 1024));
-    }
-    auto dma_piece = [&](int k, int buf, int i) {
-        const float* src = up + (size_t)k * MB * UBUF;                       // wave-uniform: SGPR base + VGPR offset
-        const unsigned dst = dm0[i] + (unsigned)buf * (unsigned)(UBUF * 4);
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
+    auto rows = [&](int r) {
+        wino_in3(xo[r].x, xm[r].x, xm[r].y, xo[r].y, t3[r]);
+        wino_in2(xo[r].x, xm[r].x, xm[r].y, t2[r]);
     };
 
     f32x4 acc[49];
@@ -259,34 +261,35 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     const int nk = p.Cin / 4;
     const int aoff = (kq * 16 + l15) * WINO_LD;
     // K step k, in MFMA quads q = 0..12 (4 transform points each, 1 for the last).  Quad q issues its 4 MFMAs on v[4q..4q+3], the
-    // points of THIS step, and then refills those registers with the points of step k+1, computed from the row transforms t3 / t2 of
-    // patch k+1 (in xl/xm/xr since the previous step).  Everything else a step needs rides in the issue slots between those MFMAs (one wave
-    // per SIMD: about five other instructions fit beside a 32-cycle MFMA), spread by hand and pinned with sched_barrier:
-    //   quads 0-3   one DMA piece of U slab k+1 each; the row transforms (t3 rows as the class-(1,1) points first need them, t2 rows
-    //               in between); after quad 3 the patch registers are dead
-    //   quads 4-7   the two loads of one row of patch k+2 each (5 quads + the barrier ahead of their first use)
+    // points of THIS step; one quad later those registers are refilled with the points of step k+1, computed from the row transforms
+    // t3 / t2 of patch k+1.  Everything else a step needs rides in the issue slots between those MFMAs (one wave per SIMD: about five other
+    // instructions fit beside a 32-cycle MFMA), spread by hand and pinned with sched_barrier:
+    //   quad 0      the 8 LDS reads of this lane's 4 x 4 patch (k+1); rows 0 and 2 transformed once they are back
+    //   quads 0-3   one DMA piece of U slab k+1 each; the remaining row transforms as the points first need them
+    //   quads 4-..  the wave's pieces of patch k+3
     //   all quads   the A operand read of quad q+2
     float v[49];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(0, 0, i);
-    {
-        const PatchSrc ps = patch_src(0);
+    for (int i = 0; i < 4; ++i) dma_u(0, 0, i);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) load_row(ps, r);
+    for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rows(r, true, true);
-        WinoFor<0, 49>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<x>(t3, t2); });
-        const PatchSrc p1 = patch_src(min(1, nk - 1));
+    for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                      // vmcnt(0)
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) load_row(p1, r);
-    }
+    for (int r = 0; r < 4; ++r) { read_row(s_p, r); rows(r); }
+    WinoFor<0, 49>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<x>(t3, t2); });
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
+    int slot = 0;                                                            // k % 3: patch k+1 is in slot+1, patch k+3 goes to `slot`
     for (int k = 0; k < nk; ++k) {
-        // vmcnt(8): everything older than the 8 loads of patch k+1 has landed - in particular this wave's DMA pieces of slab k.
-        // After the barrier so have everyone's, and every wave is done reading the other buffer.
-        if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F78); __syncthreads(); }
-        const int buf = k & 1, kd = min(k + 1, nk - 1);                      // (the last step refills the free buffer with its own slab
-        const PatchSrc ps = patch_src(min(k + 2, nk - 1));                   //  and re-reads its own patch: both unused)
+        // vmcnt(PPW): everything older than this wave's pieces of patch k+2 has landed - its pieces of U slab k and of patch k+1.
+        // After the barrier so have everyone's, and every wave is done reading U buffer (k+1)&1 and patch slot k%3.
+        if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | PPW); __syncthreads(); }
+        const int buf = k & 1, kd = min(k + 1, nk - 1), kp = min(k + 3, nk - 1);   // (past the end: refill with the last slab / patch, unused)
         const float* ub = s_u + buf * UBUF + aoff;
+        const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
         float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
         __builtin_amdgcn_sched_barrier(0);
         WinoFor<0, 13>::run([&](auto qc) {
@@ -294,23 +297,50 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
             const float4 a = a0;
             a0 = a1;
             if constexpr (q < 11 && ABL != 5) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
-            if constexpr (q == 0 && ABL != 4) { rows(0, true, true); rows(2, true, true); __builtin_amdgcn_sched_barrier(0); }     // (the compiler waits for vmcnt(0) here: before the first DMA piece)
-            if constexpr (q < 4 && ABL != 3) dma_piece(kd, buf ^ 1, q);
-            if constexpr (q == 1 && ABL != 4) { rows(1, true, true); }
-            if constexpr (q == 3 && ABL != 4) { rows(3, true, true); }                    // the patch registers are dead from here on
-            if constexpr (q >= 4 && q <= 7 && ABL != 2) load_row(ps, q - 4);
+            if constexpr (q == 0 && ABL != 4) { read_row(pbuf, 0); read_row(pbuf, 2); read_row(pbuf, 1); read_row(pbuf, 3); }
+            if constexpr (q < 4 && ABL != 3) dma_u(kd, buf ^ 1, q);
+            if constexpr (q >= 4 && q < 4 + PPW && ABL != 2) dma_patch(kp, slot, q - 4);
             acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
-            if constexpr (ABL != 4) v[4 * q] = wino_point<4 * q>(t3, t2);
             if constexpr (q < 12) {
                 acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
-                if constexpr (ABL != 4) v[4 * q + 1] = wino_point<4 * q + 1>(t3, t2);
                 acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
-                if constexpr (ABL != 4) v[4 * q + 2] = wino_point<4 * q + 2>(t3, t2);
                 acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
-                if constexpr (ABL != 4) v[4 * q + 3] = wino_point<4 * q + 3>(t3, t2);
+            }
+            // Refill, ONE QUAD LATE: a VALU write to a register that an MFMA issued just before reads as its B operand waits until the
+            // MFMA has finished reading it, and being in-order the wave cannot issue the next MFMA meanwhile (measured: refilling
+            // v[x] right behind its own MFMA ran 46 cycles per MFMA instead of 32).  Quad q therefore refills the points of quad q-1,
+            // and quad 0 the single point of quad 12 - from the OLD row transforms, before they are replaced.
+            if constexpr (ABL != 4) {
+                if constexpr (q == 0) { v[48] = wino_point<48>(t3, t2); rows(0); rows(2); }
+                if constexpr (q == 1) rows(1);
+                if constexpr (q == 3) rows(3);
+                if constexpr (q >= 1) {
+                    v[4 * q - 4] = wino_point<4 * q - 4>(t3, t2); v[4 * q - 3] = wino_point<4 * q - 3>(t3, t2);
+                    v[4 * q - 2] = wino_point<4 * q - 2>(t3, t2); v[4 * q - 1] = wino_point<4 * q - 1>(t3, t2);
+                }
+            }
+            // issue order inside the quad: MFMA, a few VALU instructions, MFMA, ... (each refill lands >= 4 MFMAs behind its reader)
+            if constexpr (q == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            } else if constexpr (q == 1 || q == 3) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            } else if constexpr (q < 12) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
             __builtin_amdgcn_sched_barrier(0);                               // quads stay in order: bounded live ranges, no accumulator copies
         });
+        slot = slot == 2 ? 0 : slot + 1;
     }
 
     // ---- output transform + bias -> activation -> batch-norm; lane = block (wave*16 + l15), channels m0 + 4*kq + r
@@ -375,7 +405,7 @@ int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 ru
 }
 int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
 {
-    if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 1)) return 1;
+    if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 3)) return 1;
     const int MB = p.Cout / 16;
     if (p.H >= 8 && p.W >= 32) {
         const long wgs = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * MB * p.nstems * p.ntiles;
