@@ -129,11 +129,9 @@ template <int X> __device__ __forceinline__ float wino_point(const float (&t3)[4
     constexpr int e = X - (cls == 0 ? WINO_C11 : cls == 1 ? WINO_C10 : cls == 2 ? WINO_C01 : WINO_C00);
     constexpr bool y3 = cls < 2, x3 = !(cls & 1);                            // 3-tap (4-point) transform along y / x
     constexpr int nx = x3 ? 4 : 3, i = e / nx, j = e % nx;
-    float c0, c1, c2, c3;
-    if constexpr (x3) { c0 = t3[0][j]; c1 = t3[1][j]; c2 = t3[2][j]; c3 = t3[3][j]; }
-    else { c0 = t2[0][j]; c1 = t2[1][j]; c2 = t2[2][j]; c3 = t2[3][j]; }
-    if constexpr (y3) return i == 0 ? c0 - c2 : i == 1 ? c1 + c2 : i == 2 ? c2 - c1 : c1 - c3;
-    else return i == 0 ? c0 - c1 : i == 1 ? c1 : c1 - c2;
+    auto c = [&](int r) { if constexpr (x3) return t3[r][j]; else return t2[r][j]; };
+    if constexpr (y3) return i == 0 ? c(0) - c(2) : i == 1 ? c(1) + c(2) : i == 2 ? c(2) - c(1) : c(1) - c(3);
+    else return i == 0 ? c(0) - c(1) : i == 1 ? c(1) : c(1) - c(2);      // (patch row 3 is not used by the even output rows)
 }
 template <int I, int N> struct WinoFor {                                    // compile-time loop: f(integral_constant<I>) ... f(integral_constant<N-1>)
     template <class F> static __device__ __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); WinoFor<I + 1, N>::run(f); }
@@ -141,40 +139,46 @@ template <int I, int N> struct WinoFor {                                    // c
 template <int N> struct WinoFor<N, N> { template <class F> static __device__ __forceinline__ void run(F&&) {} };
 
 // ------------------------------------------------------------------------------------------- the layer kernel
-// tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BA * BB == 16 * (waves per instance).
+// tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BA * BB a multiple of 16.
 // Requires H even, W % 4 == 0, Cin % 4 == 0, CA % 4 == 0, Cout % 16 == 0 (the launcher checks).
 //
-// Lane (kq = lane / 16, l15 = lane % 16) of wave w owns block 16 w + l15 and, in K step k, input channel 4 k + kq: exactly the
+// Workgroup = 8 waves = 4 block groups x 2 output-row parities.  Wave (g, h) owns blocks 16 g .. 16 g + 15 and the transform points
+// of the output rows with parity py = h: h = 1 the classes (1,1) + (1,0) = 28 points (xi 0..27), h = 0 the classes (0,1) + (0,0)
+// = 21 points (xi 28..48); waves g and g + 4 share a SIMD, so each SIMD still issues 49 MFMAs per K step.  Two waves per SIMD is
+// the point of the split: measured with one wave per SIMD holding all 49 accumulators (196 registers), every instruction issued
+// between two MFMAs of that wave cost 6-7 cycles on top of the MFMA's 32 - transform arithmetic, LDS reads, address SALU all
+// added up: 46 cycles per MFMA.  With a second wave the SIMD issues one wave's MFMAs while the other does its VALU work.
+//
+// Lane (kq = lane / 16, l15 = lane % 16) of a wave owns block 16 g + l15 and, in K step k, input channel 4 k + kq: exactly the
 // (k, n) element the 16x16x4 MFMA wants from this lane as its B operand.  So the lane transforms that block's 4 x 4 patch of that
-// channel itself, in registers, and the 49 results ARE its B operands of the K step: V never touches LDS.
+// channel itself, in registers, and the results ARE its B operands of the K step: V never touches LDS.
 //
 // Global memory reaches the CU by LDS-DMA only (no load has a register destination, so nothing in flight pins registers and the
 // prefetch distance is free to choose):
 //   U slab k+1   13 pieces of 1 KiB (global_load_lds), two buffers: lands one step ahead; weights come from the XCD's L2
 //   patch k+3    the tile's 4-channel input patch, rows ty0-1..ty0+TH, columns tx0-4..tx0+TW+3 as aligned float4s
 //                (buffer_load_dwordx4 ... lds: a float4 outside the image has an out-of-range offset and lands as zeros), three
-//                buffers: lands TWO steps ahead, because each XCD walks its own (stem, M-block) slice of the launch (weights stay
-//                in its L2) and therefore every patch is an L2 miss.  (Measured with register-destination loads issued half a
-//                step ahead: the K step waited on them for 28 % of the layer time.)
+//                buffers: lands two steps ahead - each XCD walks its own (stem, M-block) slice of the launch (the weights stay in
+//                its L2), so every patch is an L2 miss.
 // All DMA is issued from inline assembly: the compiler's own bookkeeping of LDS-DMA makes every later LDS read wait for vmcnt(0),
 // i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
-__global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
+__global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;                // patch: PH rows of PROW floats per (channel, instance)
     constexpr int PCH = NI * PH * PROW;                                      // floats per channel
-    constexpr int NF4 = 4 * PCH / 4, NPP = (NF4 + 63) / 64, PBUF = NPP * 256; // float4s, DMA pieces and floats per patch buffer
-    constexpr int PPW = (NPP + 3) / 4;                                       // pieces per wave
+    constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4s (4 channels), DMA pieces and floats per patch buffer
+    constexpr int PPW = (NPP + 7) / 8;                                       // patch pieces per wave
     __shared__ __attribute__((aligned(16))) float s_all[2 * UBUF + 3 * PBUF];
     float* s_u = s_all;
     float* s_p = s_all + 2 * UBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
     const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, MB, p.nstems, groups);
@@ -184,17 +188,17 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
     const size_t hw = (size_t)p.H * p.W;
     const float* up = U + stem * u_stem + (size_t)bc.mblk * UBUF;            // K step k at + k * MB * UBUF
 
-    const int blk = wave * 16 + l15;
+    const int blk = g * 16 + l15;
     const int il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
     const int a0 = ty0 + 2 * ba, b0 = tx0 + 2 * bb, tile = tile0 + il;
     const bool blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
 
-    // ---- U slab DMA: wave w moves pieces w, w+4, w+8, min(w+12, 12) (three waves repeat piece 12: same bytes, and no branch)
-    unsigned dvoff[4], dm0[4];                                               // byte offset inside the slab (+ lane*16), LDS byte address in buffer 0
+    // ---- U slab DMA: wave w moves pieces w and min(w + 8, 12) (three waves repeat piece 12: same bytes, and no branch)
+    unsigned dvoff[2], dm0[2];                                               // byte offset inside the slab (+ lane*16), LDS byte address in buffer 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = min(wave + 4 * i, 12);
+    for (int i = 0; i < 2; ++i) {
+        const int piece = min(wave + 8 * i, 12);
         dvoff[i] = (unsigned)(piece * 1024 + lane * 16);
         dm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(piece * 1024));
     }
@@ -204,12 +208,12 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
     };
     // ---- patch DMA: float4 e = ((c * NI + il) * PH + row) * PR4 + j of the patch buffer <- channel 4k+c, instance tile0+il,
-    // image row ty0-1+row, columns tx0-4+4j..+3.  Wave w moves pieces w, w+4, ... (a piece past the last one repeats it).
+    // image row ty0-1+row, columns tx0-4+4j..+3.  Wave w moves pieces w, w+8 (a piece past the last one repeats it).
     constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: lands as zeros
     unsigned pvoff[PPW], pm0[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int piece = min(wave + 4 * i, NPP - 1), e = piece * 64 + lane;
+        const int piece = min(wave + 8 * i, NPP - 1), e = piece * 64 + lane;
         const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
         const bool ok = e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
@@ -230,26 +234,12 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
         const unsigned dst = pm0[i] + (unsigned)slot * (unsigned)(PBUF * 4);
         asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(pvoff[i]), "s"(rs), "s"(dst), "s"(soff) : "memory");
     };
-    // ---- the transform in two stages: rows (x direction) of the patch -> t3 / t2, then one transform point at a time
     const int poff = ((kq * NI + il) * PH + 2 * ba) * PROW + 2 * bb + 3;     // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
-    float t3[4][4], t2[4][3];
-    float2 xm[4], xo[4];                                                     // patch row r: columns (b0, b0+1) | (b0-1, b0+2)
-    auto read_row = [&](const float* pbuf, int r) {
-        const float* q = pbuf + poff + r * PROW;
-        xm[r] = *reinterpret_cast<const float2*>(q + 1);                     // 8-byte aligned (2 bb + 4)
-        xo[r] = make_float2(q[0], q[3]);                                     // one ds_read2_b32
-    };
-    auto rows = [&](int r) {
-        wino_in3(xo[r].x, xm[r].x, xm[r].y, xo[r].y, t3[r]);
-        wino_in2(xo[r].x, xm[r].x, xm[r].y, t2[r]);
-    };
-
-    f32x4 acc[49];
-#pragma unroll
-    for (int x = 0; x < 49; ++x)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
-
+    const int aoff = (kq * 16 + l15) * WINO_LD;
+    const int nk = p.Cin / 4;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float* obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
     // epilogue constants before the K loop (see srt_dec16_kernel)
     float bi[4], sc[4], sf[4];
 #pragma unroll
@@ -258,119 +248,112 @@ __global__ void __launch_bounds__(256, 1) srt_dec_wino(const SrtConvParams p, co
         bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
     }
 
-    const int nk = p.Cin / 4;
-    const int aoff = (kq * 16 + l15) * WINO_LD;
-    // K step k, in MFMA quads q = 0..12 (4 transform points each, 1 for the last).  Quad q issues its 4 MFMAs on v[4q..4q+3], the
-    // points of THIS step; one quad later those registers are refilled with the points of step k+1, computed from the row transforms
-    // t3 / t2 of patch k+1.  Everything else a step needs rides in the issue slots between those MFMAs (one wave per SIMD: about five other
-    // instructions fit beside a 32-cycle MFMA), spread by hand and pinned with sched_barrier:
-    //   quad 0      the 8 LDS reads of this lane's 4 x 4 patch (k+1); rows 0 and 2 transformed once they are back
-    //   quads 0-3   one DMA piece of U slab k+1 each; the remaining row transforms as the points first need them
-    //   quads 4-..  the wave's pieces of patch k+3
-    //   all quads   the A operand read of quad q+2
-    float v[49];
+    // ---- everything below is specialised on the wave's row parity H (a wave-uniform branch; both paths run the same barriers)
+    auto body = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr int X0 = H ? 0 : 28, NP = H ? 28 : 21, NQ = H ? 7 : 6, NROW = H ? 4 : 3;   // points xi = X0 .. X0+NP-1; patch rows used
+        f32x4 acc[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_u(0, 0, i);
+        for (int x = 0; x < NP; ++x)
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
+            for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
+        // the transform in two stages: rows (x direction) of the patch -> t3 / t2, then one transform point at a time
+        float t3[4][4], t2[4][3];
+        float2 xm[4], xo[4];                                                 // patch row r: columns (b0, b0+1) | (b0-1, b0+2)
+        auto read_row = [&](const float* pbuf, int r) {
+            const float* q = pbuf + poff + r * PROW;
+            xm[r] = *reinterpret_cast<const float2*>(q + 1);
+            xo[r] = make_float2(q[0], q[3]);
+        };
+        auto rows = [&](int r) {
+            wino_in3(xo[r].x, xm[r].x, xm[r].y, xo[r].y, t3[r]);
+            wino_in2(xo[r].x, xm[r].x, xm[r].y, t2[r]);
+        };
+        // K step k, in MFMA quads q = 0..NQ-1 (4 transform points each; the last quad of H = 0 has one).  Quad q issues its MFMAs on this
+        // step's points; ONE QUAD LATER those registers are refilled with the points of step k+1, computed from the row transforms of
+        // patch k+1 (a VALU write to a register that an MFMA issued just before still reads as its B operand has to wait for it).
+        // Quad 0 first refills the last quad's points from the OLD row transforms, then reads its patch (k+1) and transforms the rows.
+        float v[NP];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                      // vmcnt(0)
-    __syncthreads();
+        for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { read_row(s_p, r); rows(r); }
-    WinoFor<0, 49>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<x>(t3, t2); });
+        for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
-    int slot = 0;                                                            // k % 3: patch k+1 is in slot+1, patch k+3 goes to `slot`
-    for (int k = 0; k < nk; ++k) {
-        // vmcnt(PPW): everything older than this wave's pieces of patch k+2 has landed - its pieces of U slab k and of patch k+1.
-        // After the barrier so have everyone's, and every wave is done reading U buffer (k+1)&1 and patch slot k%3.
-        if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | PPW); __syncthreads(); }
-        const int buf = k & 1, kd = min(k + 1, nk - 1), kp = min(k + 3, nk - 1);   // (past the end: refill with the last slab / patch, unused)
-        const float* ub = s_u + buf * UBUF + aoff;
-        const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
-        float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        WinoFor<0, 13>::run([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            const float4 a = a0;
-            a0 = a1;
-            if constexpr (q < 11 && ABL != 5) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
-            if constexpr (q == 0 && ABL != 4) { read_row(pbuf, 0); read_row(pbuf, 2); read_row(pbuf, 1); read_row(pbuf, 3); }
-            if constexpr (q < 4 && ABL != 3) dma_u(kd, buf ^ 1, q);
-            if constexpr (q >= 4 && q < 4 + PPW && ABL != 2) dma_patch(kp, slot, q - 4);
-            acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
-            if constexpr (q < 12) {
-                acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
-                acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
-                acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
-            }
-            // Refill, ONE QUAD LATE: a VALU write to a register that an MFMA issued just before reads as its B operand waits until the
-            // MFMA has finished reading it, and being in-order the wave cannot issue the next MFMA meanwhile (measured: refilling
-            // v[x] right behind its own MFMA ran 46 cycles per MFMA instead of 32).  Quad q therefore refills the points of quad q-1,
-            // and quad 0 the single point of quad 12 - from the OLD row transforms, before they are replaced.
-            if constexpr (ABL != 4) {
-                if constexpr (q == 0) { v[48] = wino_point<48>(t3, t2); rows(0); rows(2); }
-                if constexpr (q == 1) rows(1);
-                if constexpr (q == 3) rows(3);
-                if constexpr (q >= 1) {
-                    v[4 * q - 4] = wino_point<4 * q - 4>(t3, t2); v[4 * q - 3] = wino_point<4 * q - 3>(t3, t2);
-                    v[4 * q - 2] = wino_point<4 * q - 2>(t3, t2); v[4 * q - 1] = wino_point<4 * q - 1>(t3, t2);
+        for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
+        WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
+        int slot = 0;                                                        // k % 3: patch k+1 is in slot+1, patch k+3 goes to `slot`
+        for (int k = 0; k < nk; ++k) {
+            // vmcnt(PPW): everything older than this wave's pieces of patch k+2 has landed - its pieces of U slab k and of patch k+1.
+            // After the barrier so have everyone's, and every wave is done reading U buffer (k+1)&1 and patch slot k%3.
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | PPW); __syncthreads(); }
+            const int buf = k & 1, kd = min(k + 1, nk - 1), kp = min(k + 3, nk - 1);   // (past the end: refill with the last slab / patch, unused)
+            const float* ub = s_u + buf * UBUF + aoff + X0;
+            const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
+            float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            WinoFor<0, NQ>::run([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int nm = (4 * q + 4 <= NP) ? 4 : NP - 4 * q;       // MFMAs of this quad
+                const float4 a = a0;
+                a0 = a1;
+                if constexpr (q + 2 < NQ && ABL != 5) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
+                if constexpr (q == 1 && ABL != 3) { dma_u(kd, buf ^ 1, 0); dma_u(kd, buf ^ 1, 1); }
+                if constexpr (q == 2 && ABL != 2) {
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i) dma_patch(kp, slot, i);
                 }
-            }
-            // issue order inside the quad: MFMA, a few VALU instructions, MFMA, ... (each refill lands >= 4 MFMAs behind its reader)
-            if constexpr (q == 0) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            } else if constexpr (q == 1 || q == 3) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            } else if constexpr (q < 12) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);                               // quads stay in order: bounded live ranges, no accumulator copies
-        });
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-
-    // ---- output transform + bias -> activation -> batch-norm; lane = block (wave*16 + l15), channels m0 + 4*kq + r
-    if (!blk_ok) return;
-    const int Wo = p.W << 1;
-    const size_t ohw = (size_t)(p.H << 1) * Wo;
-    float* o = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(2 * a0) * Wo + 2 * b0;
+                acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
+                if constexpr (nm > 1) {
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
+                }
+                if constexpr (ABL != 4) {
+                    if constexpr (q == 0) {
+                        constexpr int l0 = 4 * (NQ - 1);                     // the last quad's points, from the old row transforms
+                        WinoFor<l0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float m[49];
+                        for (int r = 0; r < NROW; ++r) read_row(pbuf, r);
 #pragma unroll
-        for (int x = 0; x < 49; ++x) m[x] = acc[x][r];
-        float y11[2][2], y10[2][2], y01[2][2], y00[2][2];
-        wino_out2d<4, 4>(m + WINO_C11, y11);
-        wino_out2d<4, 3>(m + WINO_C10, y10);
-        wino_out2d<3, 4>(m + WINO_C01, y01);
-        wino_out2d<3, 3>(m + WINO_C00, y00);
-        float* oc = o + (size_t)(m0 + 4 * kq + r) * ohw;
-#pragma unroll
-        for (int da = 0; da < 2; ++da) {
-            // output rows 2(a0+da)+py, columns 2(b0+db)+px: one float4 = (px0 db0, px1 db0, px0 db1, px1 db1)
-            float4 e0, e1;
-            e0.x = srt_dec_epilogue(y00[da][0], bi[r], sc[r], sf[r], actp); e0.y = srt_dec_epilogue(y01[da][0], bi[r], sc[r], sf[r], actp);
-            e0.z = srt_dec_epilogue(y00[da][1], bi[r], sc[r], sf[r], actp); e0.w = srt_dec_epilogue(y01[da][1], bi[r], sc[r], sf[r], actp);
-            e1.x = srt_dec_epilogue(y10[da][0], bi[r], sc[r], sf[r], actp); e1.y = srt_dec_epilogue(y11[da][0], bi[r], sc[r], sf[r], actp);
-            e1.z = srt_dec_epilogue(y10[da][1], bi[r], sc[r], sf[r], actp); e1.w = srt_dec_epilogue(y11[da][1], bi[r], sc[r], sf[r], actp);
-            *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e0;          // py = 0
-            *reinterpret_cast<float4*>(oc + (size_t)(2 * da + 1) * Wo) = e1;      // py = 1
+                        for (int r = 0; r < NROW; ++r) rows(r);
+                    } else {
+                        WinoFor<4 * q - 4, 4 * q>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // quads stay in order: bounded live ranges, no accumulator copies
+            });
+            slot = slot == 2 ? 0 : slot + 1;
         }
-    }
+
+        // ---- output transform + bias -> activation -> batch-norm: this lane's block, channels m0 + 4*kq + r, output rows of parity H
+        if (!blk_ok) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m[NP];
+#pragma unroll
+            for (int x = 0; x < NP; ++x) m[x] = acc[x][r];
+            float yA[2][2], yB[2][2];                                        // px = 1 and px = 0 classes of this row parity
+            if constexpr (H) { wino_out2d<4, 4>(m + WINO_C11 - X0, yA); wino_out2d<4, 3>(m + WINO_C10 - X0, yB); }
+            else { wino_out2d<3, 4>(m + WINO_C01 - X0, yA); wino_out2d<3, 3>(m + WINO_C00 - X0, yB); }
+            float* oc = obase + (size_t)(m0 + 4 * kq + r) * ohw + (size_t)H * Wo;
+#pragma unroll
+            for (int da = 0; da < 2; ++da) {
+                // output row 2(a0+da)+H, columns 2(b0+db)+px: one float4 = (px0 db0, px1 db0, px0 db1, px1 db1)
+                float4 e;
+                e.x = srt_dec_epilogue(yB[da][0], bi[r], sc[r], sf[r], actp); e.y = srt_dec_epilogue(yA[da][0], bi[r], sc[r], sf[r], actp);
+                e.z = srt_dec_epilogue(yB[da][1], bi[r], sc[r], sf[r], actp); e.w = srt_dec_epilogue(yA[da][1], bi[r], sc[r], sf[r], actp);
+                *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e;
+            }
+        }
+    };
+    if (h) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
 }
 
 // ------------------------------------------------------------------------------------------- launcher
@@ -412,18 +395,18 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         if (wgs < 256 && !srt_wino_force()) return 1;                        // small batches: the split-K direct kernels
 #ifdef SRT_TUNING
         switch (wino_tune("winoabl=")) {
-        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
-        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
-        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
-        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
-        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem); return 0;
+        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
+        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
+        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
+        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
+        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
         }
 #endif
-        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem);
+        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
     } else if (p.H >= 4 && p.W >= 16) {
         const long wgs = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * MB * p.nstems * ((p.ntiles + 3) / 4);
         if (wgs < 256 && !srt_wino_force()) return 1;
-        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)wgs), dim3(256), 0, s, p, U, u_stem);
+        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
     } else return 1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
