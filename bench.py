@@ -42,12 +42,15 @@ LAYER_SYMBOL = {
     "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false, false>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 2, false, 0, false, false>",
     "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false, false>", "down4": "srt_enc_mfma2<128, 2, 32, 2, 4, 1, 2, false, 0, false, false>",
     "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false, false>",
-    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false, false>", "up2": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false, false>",
-    "up3": "srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, 0, false, false>", "up4": "srt_dec_mfma2<32, 1, 32, 2, 4, 1, 4, false, 0, false, false>",
-    "up5": "srt_dec16_kernel<4, 4, 4>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",
+    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false, false>", "up2": "srt_dec_wino<4, 16, 1, 0>",
+    "up3": "srt_dec_wino<4, 16, 1, 0>", "up4": "srt_dec_wino<4, 16, 1, 0>",
+    "up5": "srt_dec_wino<4, 16, 1, 0>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",
 }
+# Layers that run in Winograd form (csrc/srt_nn4.hip): the MFMAs EXECUTE 49 products per 2x2 input block where the layer's algorithm
+# (LAYER_FLOP, the reference's direct transposed convolution) has 100.  `achieved` stays algorithmic; `executed` is reported beside it.
+WINO_EXECUTED_FRACTION = 0.49
 # written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")]
 N_SIMD = 1024                               # 256 CUs x 4 SIMDs: SQ_VALU_MFMA_BUSY_CYCLES is summed over them
 
 
@@ -281,6 +284,12 @@ def main():
                          "mfma_busy_frac": mfma_busy,
                          "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the launch at the clock the chip held, GRBM_GUI_ACTIVE/8); frac is against the 2.4 GHz peak",
                          "flop_per_launch": dom_flop, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],
+                         **({"executed": {"flop_per_launch": dom_flop * WINO_EXECUTED_FRACTION,
+                                          "achieved": dom_tflops * WINO_EXECUTED_FRACTION, "unit": "TFLOP/s",
+                                          "frac": dom_tflops * WINO_EXECUTED_FRACTION / PEAK_F32_MFMA_TFLOPS,
+                                          "note": "Winograd F(2,3)/F(2,2) form: the kernel issues 49 MFMA products per 2x2 input block where the direct "
+                                                  "transposed convolution counted in `achieved` has 100; `frac` above can therefore exceed 1, this one cannot"}}
+                            if "wino" in dom else {}),
                          "share_of_step": sym_ms[dom] / (dt_ev / a.steps * 1e3),
                          # the whole path against the MFMA roofline: algorithmic network FLOP of one step / wall time of one step
                          "step": {"achieved": nn_flop / (step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

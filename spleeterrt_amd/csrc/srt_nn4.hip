@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 // Which decoder layers (bit i = up(i+1)) run this form.  The default is the set measured faster than the direct kernels on
 // MI355X at 64 tiles x 4 stems; a -DSRT_TUNING build overrides it with SRT_TUNE=wino=<mask>.
 #ifndef SRT_WINO_DEFAULT_MASK
-#define SRT_WINO_DEFAULT_MASK 0
+#define SRT_WINO_DEFAULT_MASK 30      // up2..up5 (up1: 0.80 vs 0.79 ms for the direct kernel at 64 tiles x 4 stems)
 #endif
 #ifdef SRT_TUNING
 static int wino_tune(const char* key)                                        // key includes the '='
@@ -392,7 +392,6 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
     const int MB = p.Cout / 16;
     if (p.H >= 8 && p.W >= 32) {
         const long wgs = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * MB * p.nstems * p.ntiles;
-        if (wgs < 256 && !srt_wino_force()) return 1;                        // small batches: the split-K direct kernels
 #ifdef SRT_TUNING
         switch (wino_tune("winoabl=")) {
         case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
@@ -405,7 +404,6 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
     } else if (p.H >= 4 && p.W >= 16) {
         const long wgs = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * MB * p.nstems * ((p.ntiles + 3) / 4);
-        if (wgs < 256 && !srt_wino_force()) return 1;
         hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
     } else return 1;
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -58,6 +58,33 @@ def test_forward_layers(oracle, coeffs, impl, T, F):
     print("forward %s %dx%d worst mask err %.3g" % (impl, T, F, worst))
 
 
+@pytest.mark.parametrize("T,F,check", [(64, 512, (0, 4, 8)), (128, 1024, (8,))])
+def test_winograd_decoder_layers(oracle, coeffs, T, F, check):
+    """Batches above 16 instances run the decoder layers up2..up5 in their Winograd form (csrc/srt_nn4.hip: F(2,3)/F(2,2) over 2x2 input
+    blocks, 49 MFMA products per block instead of 100).  9 tiles x 2 stems = 18 instances: every tensor of the sampled tiles against the
+    oracle at the same tolerance as the direct kernels.  9 is not a multiple of the 4-instance tile of the deep layers (a partly empty
+    instance group), T = 64 leaves up2 below the smallest tile (it stays on the direct kernel), T = 128 covers up2."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = (0, 1)
+    ntiles = 9
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, impl=srt.IMPL_MFMA)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=99)
+    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.isfinite(masks).all()
+    for s in range(2):
+        for t in check:
+            y, taps = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST, want_taps=True)
+            for name, ref in taps.items():
+                got = eng.tensor(name, s, t)
+                err = _rel_rms(got, ref)
+                assert err < 2e-5, "%s stem %d tile %d: rel rms %g, max abs %g" % (name, s, t, err, np.abs(got - ref).max())
+            assert np.abs(masks[s, t] - y).max() <= MASK_TOL_EXACT
+    eng.close()
+
+
 def test_forward_lut_variant(oracle, coeffs):
     import torch
     import spleeterrt_amd as srt
