@@ -14,18 +14,16 @@
 //                     of the taps), stored [Cin/4][Cout/16][4][16][52] so that a workgroup's slab of a 4-channel K step is
 //                     13 KiB of contiguous memory, moved by 13 LDS-DMA instructions;
 //   V = B_y X B_x^T   the transformed 4 x 4 input patch (rows a0-1..a0+2, columns b0-1..b0+2) of the block: additions and
-//                     subtractions only, ~65 VALU instructions per thread and K step, written to LDS [ci][block][52];
+//                     subtractions only, computed in registers by the lane that needs it as its MFMA B operand (see the kernel);
 //   Y = A_y M A_x^T   the 2 x 2 outputs of the class, then bias -> activation -> batch-norm (spleeter.c:244-245).
 //
-// Workgroup = 16 output channels x 64 blocks; wave w owns blocks 16w..16w+15 and keeps all 49 accumulators of its
-// 16 x 16 tile (196 registers); a lane's k index is the input channel of the K step, so an A (B) fragment for four
-// consecutive xi is ONE ds_read_b128: 26 LDS reads feed the 49 MFMAs of a K step.  V and U are double buffered in LDS
-// (130 KB: one workgroup per CU, one wave per SIMD), so a K step has a single barrier: the next patch's global loads, its
-// transform and the next U slab's DMA are issued in the shadow of the current step's MFMAs.
+// Workgroup = 16 output channels x 64 blocks, 8 waves: 4 groups of 16 blocks x 2 output-row parities (the kernel's comment has
+// the details and DESIGN.md section 3.2a the measurements that led there).  Used for up2..up5 when the batch has more than 16
+// instances; smaller batches and up1 stay on the direct kernels of srt_nn2.hip.
 //
 // Numerics: U is exact up to one rounding per point (sums of at most 9 weights, scaled by 1/2 or 1/4); V and Y add one or two
 // roundings of additions.  The F(2,3)/F(2,2) matrices have entries 0, +-1, 1/2 only, so there is none of the cancellation
-// that larger Winograd tiles are known for; measured against the oracle the layer outputs agree to ~1e-6 relative.
+// that larger Winograd tiles are known for; the layer outputs agree with the CPU reference to ~1e-6 relative (tests/test_gpu_parity.py).
 #include "srt_device.h"
 #include <cstdlib>
 #include <cstring>
@@ -378,7 +376,7 @@ int srt_wino_mask()
 #endif
     return SRT_WINO_DEFAULT_MASK;
 }
-int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 runs this form for small batches too (parity tests at oracle sizes)
+int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 runs this form for small batches too (parity tests at CPU-reference sizes)
 {
 #ifdef SRT_TUNING
     return wino_tune("winoforce=") > 0;

@@ -1,0 +1,62 @@
+"""CPU check of the algebra behind csrc/srt_nn4.hip: the 5x5 stride-2 transposed convolution of the decoder
+(Executable/spleeter.c:239-294 via conv_transpose2d) equals, per output parity class (py, px), Winograd minimal filtering over
+2x2 input blocks - F(2,3) along an axis with 3 taps (k = 4, 2, 0), F(2,2) along one with 2 taps (k = 3, 1) - with the transform
+matrices, tap order, patch origin (rows a0-1..a0+2, columns b0-1..b0+2) and point count (16 + 12 + 12 + 9 = 49) the kernel uses.
+Pure numpy, float64, tiny sizes; the GPU tests hold the kernel itself against the oracle."""
+import numpy as np
+
+B3 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)      # 4 points from d0..d3
+B2 = np.array([[1, -1, 0, 0], [0, 1, 0, 0], [0, 1, -1, 0]], float)                      # 3 points from d0..d2 (d3 unused)
+G3 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], float)               # taps (g[-1], g[0], g[+1])
+G2 = np.array([[1, 0], [1, 1], [0, 1]], float)                                          # taps (g[-1], g[0])
+A3 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
+A2 = np.array([[1, 1, 0], [0, 1, -1]], float)
+BT, GT, AT = {1: B3, 0: B2}, {1: G3, 0: G2}, {1: A3, 0: A2}
+
+
+def taps(p):                        # (input shift d, kernel index k = p + 1 - 2 d)
+    return [(-1, 4), (0, 2), (1, 0)] if p == 1 else [(-1, 3), (0, 1)]
+
+
+def direct(x, w):
+    cin, cout, H, W = x.shape[0], w.shape[1], x.shape[1], x.shape[2]
+    y = np.zeros((cout, 2 * H, 2 * W))
+    for h in range(H):
+        for ww in range(W):
+            for ky in range(5):
+                for kx in range(5):
+                    Y, X = 2 * h + ky - 1, 2 * ww + kx - 1
+                    if 0 <= Y < 2 * H and 0 <= X < 2 * W:
+                        y[:, Y, X] += w[:, :, ky, kx].T @ x[:, h, ww]
+    return y
+
+
+def winograd(x, w):
+    cin, cout, H, W = x.shape[0], w.shape[1], x.shape[1], x.shape[2]
+    xp = np.zeros((cin, H + 3, W + 3))
+    xp[:, 1:H + 1, 1:W + 1] = x
+    y = np.zeros((cout, 2 * H, 2 * W))
+    npts = 0
+    for py in (1, 0):
+        for px in (1, 0):
+            g = np.stack([np.stack([w[:, :, ky, kx] for (_, kx) in taps(px)], -1) for (_, ky) in taps(py)], -2)
+            U = np.einsum('ik,cokl,jl->coij', GT[py], g, GT[px])
+            npts += U.shape[2] * U.shape[3]
+            for a0 in range(0, H, 2):
+                for b0 in range(0, W, 2):
+                    V = np.einsum('ik,ckl,jl->cij', BT[py], xp[:, a0:a0 + 4, b0:b0 + 4], BT[px])
+                    Yb = np.einsum('ik,okl,jl->oij', AT[py], np.einsum('coij,cij->oij', U, V), AT[px])
+                    for da in range(2):
+                        for db in range(2):
+                            y[:, 2 * (a0 + da) + py, 2 * (b0 + db) + px] = Yb[:, da, db]
+    return y, npts
+
+
+def test_transposed_conv_equals_winograd_classes():
+    rng = np.random.default_rng(7)
+    for (cin, cout, H, W) in ((3, 2, 6, 8), (1, 1, 2, 4), (2, 3, 4, 4)):
+        x = rng.standard_normal((cin, H, W))
+        w = rng.standard_normal((cin, cout, 5, 5))
+        y, npts = winograd(x, w)
+        assert npts == 49
+        assert np.abs(y - direct(x, w)).max() < 1e-12
