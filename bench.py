@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f16x2"],
                     help="conv contraction arithmetic; the headline metric is f32 (other modes are separate, labelled configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stem-modes", default="1" * STEMS, help="per stem: 1 = ELU/ELU (the 4-stem model), 0 = LeakyReLU/ReLU; measurement aid")
     ap.add_argument("--cpu-tiles", type=int, default=0)
     ap.add_argument("--config", default="c3", choices=["c3", "c4"],
                     help="c3 (default, the headline): BASELINE configs[2], 64-tile batches resident in HBM.  c4: BASELINE configs[3], the "
@@ -174,7 +175,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
-    eng = srt.Engine(F=F, T=T, stem_modes=(1,) * STEMS, oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST,
+    eng = srt.Engine(F=F, T=T, stem_modes=tuple(int(c) for c in a.stem_modes), oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST,
                      max_tiles=a.tiles, impl=srt.IMPL_NAIVE if a.impl == "naive" else srt.IMPL_MFMA, device=dev,
                      precision={"f32": srt.PREC_F32, "f16": srt.PREC_F16, "f16x2": srt.PREC_F16X2}[a.precision])
     # weights: rank 0 creates them, one RCCL broadcast per blob (the only collective on this path)
