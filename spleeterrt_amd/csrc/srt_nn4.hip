@@ -162,7 +162,7 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
-__global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem)
+__global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
@@ -179,17 +179,19 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, MB, p.nstems, groups);
-    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH;
-    const int m0 = bc.mblk * 16, stem = bc.stem, tile0 = bc.grp * NI;
+    // A workgroup walks `tpw` consecutive (instance group, spatial tile) units of one (stem, M block): same U slabs, and the first
+    // DMA of the next unit is issued BEFORE the epilogue of the current one, so its latency hides under the output transform and
+    // the stores (at one workgroup per CU nothing else would cover it).  Launch order as srt_block_coord: (stem, M block) slowest.
+    const int nsp = tilesX * tilesY, upw = nsp * groups / tpw;               // workgroups per (stem, M block)
+    const int pos = srt_xcd_order(upw * MB * p.nstems);
+    const int wsel = pos / upw, mblk = wsel % MB, stem = wsel / MB, unit0 = (pos % upw) * tpw;
+    const int m0 = mblk * 16;
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
-    const float* up = U + stem * u_stem + (size_t)bc.mblk * UBUF;            // K step k at + k * MB * UBUF
+    const float* up = U + stem * u_stem + (size_t)mblk * UBUF;               // K step k at + k * MB * UBUF
 
     const int blk = g * 16 + l15;
     const int il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
-    const int a0 = ty0 + 2 * ba, b0 = tx0 + 2 * bb, tile = tile0 + il;
-    const bool blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
 
     // ---- U slab DMA: wave w moves pieces w and min(w + 8, 12) (three waves repeat piece 12: same bytes, and no branch)
@@ -209,18 +211,23 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     // image row ty0-1+row, columns tx0-4+4j..+3.  Wave w moves pieces w, w+8 (a piece past the last one repeats it).
     constexpr unsigned OOR = 0x80000000u;                                    // >= num_records: lands as zeros
     unsigned pvoff[PPW], pm0[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int piece = min(wave + 8 * i, NPP - 1), e = piece * 64 + lane;
-        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
-        const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
-        const bool ok = e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-        pvoff[i] = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;      // srcA_tile == srcB_tile (launcher)
-        pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * UBUF * 4 + piece * 1024));
-    }
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
-    const float* pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;     // wave-uniform
-    const float* pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
+    const float* pa; const float* pb;                                        // wave-uniform: channel 0 of the unit's first instance
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
+    auto set_dma_unit = [&](int unit) {
+        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = min(wave + 8 * i, NPP - 1), e = piece * 64 + lane;
+            const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+            const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
+            const bool ok = e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            pvoff[i] = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;  // srcA_tile == srcB_tile (launcher)
+        }
+        pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;
+        pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
+    };
     const int kA = p.CA / 4;                                                 // K steps [0, kA) read srcA, the rest srcB (CA % 4 == 0)
     const unsigned kstep_bytes = (unsigned)(16 * hw);                        // 4 channels
     auto dma_patch = [&](int k, int slot, int i) {
@@ -237,7 +244,12 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const int nk = p.Cin / 4;
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
-    float* obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
+    float* obase; bool blk_ok;
+    auto set_out_unit = [&](int unit) {
+        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
+        blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
+        obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
+    };
     // epilogue constants before the K loop (see srt_dec16_kernel)
     float bi[4], sc[4], sf[4];
 #pragma unroll
@@ -251,10 +263,6 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         constexpr int H = decltype(hc)::value;
         constexpr int X0 = H ? 0 : 28, NP = H ? 28 : 21, NQ = H ? 7 : 6, NROW = H ? 4 : 3;   // points xi = X0 .. X0+NP-1; patch rows used
         f32x4 acc[NP];
-#pragma unroll
-        for (int x = 0; x < NP; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
         // the transform in two stages: rows (x direction) of the patch -> t3 / t2, then one transform point at a time
         float t3[4][4], t2[4][3];
         float2 xm[4], xo[4];                                                 // patch row r: columns (b0, b0+1) | (b0-1, b0+2)
@@ -272,13 +280,22 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         // patch k+1 (a VALU write to a register that an MFMA issued just before still reads as its B operand has to wait for it).
         // Quad 0 first refills the last quad's points from the OLD row transforms, then reads its patch (k+1) and transforms the rows.
         float v[NP];
+        auto issue_first = [&]() {                                           // U slab 0 -> buffer 0, patches 0 and 1 -> slots 0 and 1 of the unit set by set_dma_unit
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
+            for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
+            for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+            for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
+        };
+        set_dma_unit(unit0);
+        issue_first();
+        for (int t = 0; t < tpw; ++t) {
+#pragma unroll
+        for (int x = 0; x < NP; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the unit's first slab and patches (and whatever the previous unit left in flight)
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
@@ -329,8 +346,17 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
             slot = slot == 2 ? 0 : slot + 1;
         }
 
+        // ---- the next unit's first DMA goes out before this unit's epilogue.  Barrier: every wave is out of the K loop, so the U
+        // buffers and patch slots are free (the refills the last K steps issued past the end target the same pieces from the same
+        // waves, earlier in each wave's DMA order, so they land first).
+        if (t + 1 < tpw) {
+            __syncthreads();
+            set_dma_unit(unit0 + t + 1);
+            issue_first();
+        }
         // ---- output transform + bias -> activation -> batch-norm: this lane's block, channels m0 + 4*kq + r, output rows of parity H
-        if (!blk_ok) return;
+        set_out_unit(unit0 + t);
+        if (blk_ok) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float m[NP];
@@ -349,6 +375,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                 *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e;
             }
         }
+        }
+        }                                                                    // units
     };
     if (h) body(std::integral_constant<int, 1>{});
     else body(std::integral_constant<int, 0>{});
@@ -384,25 +412,40 @@ int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 ru
     return 0;
 #endif
 }
+// workgroups that walk `tpw` units each: up to 4 (measured: 1 -> 4 takes up5 from 1.43 to 1.34 ms, up4 1.24 -> 1.20, up2 1.12 -> 1.10),
+// as long as it divides the units of a (stem, M block) and leaves two workgroups per CU
+static int wino_tpw(long wgs, long units)
+{
+#ifdef SRT_TUNING
+    const int t = wino_tune("winotpw=");
+    if (t > 0 && units % t == 0) return t;
+#endif
+    int tpw = 1;
+    while (tpw < 4 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
+    return tpw;
+}
 int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
 {
     if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 3)) return 1;
     const int MB = p.Cout / 16;
     if (p.H >= 8 && p.W >= 32) {
-        const long wgs = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * MB * p.nstems * p.ntiles;
+        const long units = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * p.ntiles, wgs = units * MB * p.nstems;
+        const int tpw = wino_tpw(wgs, units);
+        const dim3 grid((unsigned)(wgs / tpw));
 #ifdef SRT_TUNING
         switch (wino_tune("winoabl=")) {
-        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
-        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
-        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
-        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
-        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem); return 0;
+        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         }
 #endif
-        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
+        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
     } else if (p.H >= 4 && p.W >= 16) {
-        const long wgs = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * MB * p.nstems * ((p.ntiles + 3) / 4);
-        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)wgs), dim3(512), 0, s, p, U, u_stem);
+        const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 3) / 4), wgs = units * MB * p.nstems;
+        const int tpw = wino_tpw(wgs, units);
+        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
     } else return 1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
