@@ -153,7 +153,8 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 //
 // Global memory reaches the CU by LDS-DMA only (no load has a register destination, so nothing in flight pins registers and the
 // prefetch distance is free to choose):
-//   U slab k+1   13 pieces of 1 KiB (global_load_lds), two buffers: lands one step ahead; weights come from the XCD's L2
+//   U slab k+2   13 pieces of 1 KiB (global_load_lds), three buffers: lands two steps ahead (one step is enough while the slab sits in the
+//                XCD's L2; the deep layers with few workgroups per (stem, M block) keep several slabs in flight per XCD and miss)
 //   patch k+3    the tile's 4-channel input patch, rows ty0-1..ty0+TH, columns tx0-4..tx0+TW+3 as aligned float4s
 //                (buffer_load_dwordx4 ... lds: a float4 outside the image has an out-of-range offset and lands as zeros), three
 //                buffers: lands two steps ahead - each XCD walks its own (stem, M-block) slice of the launch (the weights stay in
@@ -171,9 +172,9 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     constexpr int PCH = NI * PH * PROW;                                      // floats per channel
     constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4s (4 channels), DMA pieces and floats per patch buffer
     constexpr int PPW = (NPP + 7) / 8;                                       // patch pieces per wave
-    __shared__ __attribute__((aligned(16))) float s_all[2 * UBUF + 3 * PBUF];
+    __shared__ __attribute__((aligned(16))) float s_all[3 * UBUF + 3 * PBUF];
     float* s_u = s_all;
-    float* s_p = s_all + 2 * UBUF;
+    float* s_p = s_all + 3 * UBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
     const float* pa; const float* pb;                                        // wave-uniform: channel 0 of the unit's first instance
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(3 * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
     auto set_dma_unit = [&](int unit) {
         const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
 #pragma unroll
@@ -280,9 +281,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         // patch k+1 (a VALU write to a register that an MFMA issued just before still reads as its B operand has to wait for it).
         // Quad 0 first refills the last quad's points from the OLD row transforms, then reads its patch (k+1) and transforms the rows.
         float v[NP];
-        auto issue_first = [&]() {                                           // U slab 0 -> buffer 0, patches 0 and 1 -> slots 0 and 1 of the unit set by set_dma_unit
+        auto issue_first = [&]() {                                           // U slabs 0, 1 -> buffers 0, 1; patches 0, 1 -> slots 0, 1 of the unit set by set_dma_unit
 #pragma unroll
             for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma_u(min(1, nk - 1), 1, i);
 #pragma unroll
             for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
 #pragma unroll
@@ -302,13 +305,15 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
-        int slot = 0;                                                        // k % 3: patch k+1 is in slot+1, patch k+3 goes to `slot`
+        int slot = 0;                                                        // k % 3: U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+3 goes to `slot`
         for (int k = 0; k < nk; ++k) {
-            // vmcnt(PPW): everything older than this wave's pieces of patch k+2 has landed - its pieces of U slab k and of patch k+1.
-            // After the barrier so have everyone's, and every wave is done reading U buffer (k+1)&1 and patch slot k%3.
-            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | PPW); __syncthreads(); }
-            const int buf = k & 1, kd = min(k + 1, nk - 1), kp = min(k + 3, nk - 1);   // (past the end: refill with the last slab / patch, unused)
-            const float* ub = s_u + buf * UBUF + aoff + X0;
+            // vmcnt(2 + PPW): everything older than this wave's pieces of U slab k+1 and patch k+2 (issued in step k-1) has landed - its
+            // pieces of U slab k and of patch k+1.  After the barrier so have everyone's, and every wave is done with step k-1: U buffer
+            // (k+2)%3 and patch slot k%3 are free.
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | (2 + PPW)); __syncthreads(); }
+            const int kd = min(k + 2, nk - 1), kp = min(k + 3, nk - 1);      // (past the end: refill with the last slab / patch, unused)
+            const int ubn = slot == 0 ? 2 : slot - 1;                        // (k + 2) % 3
+            const float* ub = s_u + slot * UBUF + aoff + X0;
             const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
             float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
             __builtin_amdgcn_sched_barrier(0);
@@ -318,7 +323,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                 const float4 a = a0;
                 a0 = a1;
                 if constexpr (q + 2 < NQ && ABL != 5) a1 = *reinterpret_cast<const float4*>(ub + 4 * (q + 2));      // two quads ahead
-                if constexpr (q == 1 && ABL != 3) { dma_u(kd, buf ^ 1, 0); dma_u(kd, buf ^ 1, 1); }
+                if constexpr (q == 1 && ABL != 3) { dma_u(kd, ubn, 0); dma_u(kd, ubn, 1); }
                 if constexpr (q == 2 && ABL != 2) {
 #pragma unroll
                     for (int i = 0; i < PPW; ++i) dma_patch(kp, slot, i);
