@@ -23,7 +23,10 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC,
 SO_TUNING = os.path.join(PKG, "libspleeterrt_amd_tuning.so")
 # per-file flags.  srt_nn4.hip: no SLP vectorisation - packed f32 adds (v_pk_add_f32) beside MFMAs cost more than the two scalar adds
 # they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and its transform arithmetic is issued in the MFMAs' shadow.
-FILE_FLAGS = {"srt_nn4.hip": os.environ.get("SRT_NN4_FLAGS", "-fno-slp-vectorize").split()}
+FILE_FLAGS = {"srt_nn4.hip": ["-fno-slp-vectorize"]}
+for _kv in os.environ.get("SRT_FILE_FLAGS", "").split(";"):                # measurement aid: "srt_nn2.hip=-fno-slp-vectorize;srt_nn4.hip=-O3"
+    if "=" in _kv:
+        FILE_FLAGS[_kv.split("=", 1)[0]] = _kv.split("=", 1)[1].split()
 
 
 def sources():

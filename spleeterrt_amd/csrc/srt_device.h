@@ -36,6 +36,14 @@ __device__ __forceinline__ float srt_act_apply(float x, const SrtAct& a)
     const float neg = a.lin * x + a.ue * e;
     return x >= 0.0f ? x : neg;
 }
+// The same values with fewer instructions, for code that takes the activation kind as a workgroup-uniform branch (the fp32 MFMA
+// shares the vector ALU with every other VALU instruction, so instruction count is what these paths cost):
+//   LeakyReLU / ReLU   max(x, lin*x)                      lin in [0, 1): x >= 0 picks x, x < 0 picks lin*x       (2 instructions, was 3)
+//   ELU, no clamp      max(x, 0) + (exp(min(x, 0)) - 1)   x >= 0: x + 0, x < 0: 0 + (exp(x) - 1)                 (6, was 11 with the selects)
+// Both give bit-identical results to srt_act_apply except for the sign of a zero.
+__device__ __forceinline__ float srt_act_linear(float x, float lin) { return fmaxf(x, lin * x); }
+__device__ __forceinline__ float srt_act_elu_noclamp(float x) { return fmaxf(x, 0.0f) + (__expf(fminf(x, 0.0f)) - 1.0f); }
+__device__ __forceinline__ bool srt_act_is_plain_elu(const SrtAct& a) { return a.ue != 0.0f && a.thr == -__builtin_huge_valf(); }
 __device__ __forceinline__ float srt_enc_epilogue(float v, float scale, float shift, const SrtAct& a)
 {
     return srt_act_apply(scale * v + shift, a);                          // spleeter.c:188: act(bn[C+s]*v + bn[s])
@@ -52,23 +60,25 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
 // this much arithmetic into a divergent branch per element.  The ELU / non-ELU choice is workgroup-uniform (a scalar branch),
 // so LeakyReLU stems do not pay for a v_exp_f32 per staged value.  Same operations, same order as srt_enc_epilogue.
 __device__ __forceinline__ float srt_bn(float v, float scale, float shift) { return scale * v + shift; }      // contraction is off here
-__device__ __forceinline__ float srt_act_lin(float x, const SrtAct& a) { return x >= 0.0f ? x : a.lin * x; }   // LeakyReLU / ReLU stems
+__device__ __forceinline__ float srt_act_lin(float x, const SrtAct& a) { return fmaxf(x, a.lin * x); }       // LeakyReLU / ReLU stems (lin in [0, 1))
 __device__ __forceinline__ float srt_enc_input1(float v, float scale, float shift, const SrtAct& a)
 {
     const float x = scale * v + shift;
-    if (a.ue != 0.0f) return srt_act_apply(x, a);
-    return x >= 0.0f ? x : a.lin * x;
+    if (a.ue != 0.0f) return srt_act_is_plain_elu(a) ? srt_act_elu_noclamp(x) : srt_act_apply(x, a);
+    return srt_act_linear(x, a.lin);
 }
 __device__ __forceinline__ float4 srt_enc_input4(float4 v, float scale, float shift, const SrtAct& a)
 {
     float4 o;
+    const float x0 = scale * v.x + shift, x1 = scale * v.y + shift, x2 = scale * v.z + shift, x3 = scale * v.w + shift;
     if (a.ue != 0.0f) {
-        o.x = srt_act_apply(scale * v.x + shift, a); o.y = srt_act_apply(scale * v.y + shift, a);
-        o.z = srt_act_apply(scale * v.z + shift, a); o.w = srt_act_apply(scale * v.w + shift, a);
+        if (srt_act_is_plain_elu(a)) {                                       // VST flavour (no -15 clamp): the common case
+            o.x = srt_act_elu_noclamp(x0); o.y = srt_act_elu_noclamp(x1); o.z = srt_act_elu_noclamp(x2); o.w = srt_act_elu_noclamp(x3);
+        } else {
+            o.x = srt_act_apply(x0, a); o.y = srt_act_apply(x1, a); o.z = srt_act_apply(x2, a); o.w = srt_act_apply(x3, a);
+        }
     } else {
-        const float x0 = scale * v.x + shift, x1 = scale * v.y + shift, x2 = scale * v.z + shift, x3 = scale * v.w + shift;
-        o.x = x0 >= 0.0f ? x0 : a.lin * x0; o.y = x1 >= 0.0f ? x1 : a.lin * x1;
-        o.z = x2 >= 0.0f ? x2 : a.lin * x2; o.w = x3 >= 0.0f ? x3 : a.lin * x3;
+        o.x = srt_act_linear(x0, a.lin); o.y = srt_act_linear(x1, a.lin); o.z = srt_act_linear(x2, a.lin); o.w = srt_act_linear(x3, a.lin);
     }
     return o;
 }

@@ -193,7 +193,13 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
                 const float a = s_ibn[c0 + cix[i]], b = s_ibn[SRT_ENC_MAX_CIN + c0 + cix[i]];
                 sc[i] = ok ? a : 0.0f; sf[i] = ok ? b : 0.0f;
             }
-            if (actp.ue != 0.0f) {
+            if (srt_act_is_plain_elu(actp)) {                                  // ELU without the -15 clamp (VST flavour): 6 instructions per value
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    pin[i].x = srt_act_elu_noclamp(srt_bn(pin[i].x, sc[i], sf[i])); pin[i].y = srt_act_elu_noclamp(srt_bn(pin[i].y, sc[i], sf[i]));
+                    pin[i].z = srt_act_elu_noclamp(srt_bn(pin[i].z, sc[i], sf[i])); pin[i].w = srt_act_elu_noclamp(srt_bn(pin[i].w, sc[i], sf[i]));
+                }
+            } else if (actp.ue != 0.0f) {
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
                     pin[i].x = srt_act_apply(srt_bn(pin[i].x, sc[i], sf[i]), actp); pin[i].y = srt_act_apply(srt_bn(pin[i].y, sc[i], sf[i]), actp);
