@@ -53,6 +53,17 @@ __device__ __forceinline__ float srt_dec_epilogue(float acc, float bias, float s
     const float v = srt_act_apply(acc + bias, a);                        // spleeter.c:244-245: activation BEFORE BN
     return scale * v + shift;
 }
+// decoder epilogue with the activation kind resolved by the caller's uniform branch (same values as srt_dec_epilogue)
+__device__ __forceinline__ float srt_dec_epilogue_elu(float acc, float bias, float scale, float shift)
+{
+    const float v = srt_act_elu_noclamp(acc + bias);
+    return scale * v + shift;
+}
+__device__ __forceinline__ float srt_dec_epilogue_lin(float acc, float bias, float scale, float shift, float lin)
+{
+    const float v = srt_act_linear(acc + bias, lin);
+    return scale * v + shift;
+}
 // Consumer-side form of the encoder's batch-norm + activation (spleeter.c:188): the producing layer stores conv + bias once
 // (the skip tensor) and the next encoder layer applies act(scale * v + shift) to the four staged values of one channel.
 // Padding must stay exactly zero: the CALLER passes scale = shift = 0 for padded elements (their staged value is 0 or any finite

@@ -361,25 +361,29 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         }
         // ---- output transform + bias -> activation -> batch-norm: this lane's block, channels m0 + 4*kq + r, output rows of parity H
         set_out_unit(unit0 + t);
-        if (blk_ok) {
+        auto emit = [&](auto act) {                                          // act(y, r): bias -> activation -> batch-norm of channel r
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float m[NP];
+            for (int r = 0; r < 4; ++r) {
+                float m[NP];
 #pragma unroll
-            for (int x = 0; x < NP; ++x) m[x] = acc[x][r];
-            float yA[2][2], yB[2][2];                                        // px = 1 and px = 0 classes of this row parity
-            if constexpr (H) { wino_out2d<4, 4>(m + WINO_C11 - X0, yA); wino_out2d<4, 3>(m + WINO_C10 - X0, yB); }
-            else { wino_out2d<3, 4>(m + WINO_C01 - X0, yA); wino_out2d<3, 3>(m + WINO_C00 - X0, yB); }
-            float* oc = obase + (size_t)(m0 + 4 * kq + r) * ohw + (size_t)H * Wo;
+                for (int x = 0; x < NP; ++x) m[x] = acc[x][r];
+                float yA[2][2], yB[2][2];                                    // px = 1 and px = 0 classes of this row parity
+                if constexpr (H) { wino_out2d<4, 4>(m + WINO_C11 - X0, yA); wino_out2d<4, 3>(m + WINO_C10 - X0, yB); }
+                else { wino_out2d<3, 4>(m + WINO_C01 - X0, yA); wino_out2d<3, 3>(m + WINO_C00 - X0, yB); }
+                float* oc = obase + (size_t)(m0 + 4 * kq + r) * ohw + (size_t)H * Wo;
 #pragma unroll
-            for (int da = 0; da < 2; ++da) {
-                // output row 2(a0+da)+H, columns 2(b0+db)+px: one float4 = (px0 db0, px1 db0, px0 db1, px1 db1)
-                float4 e;
-                e.x = srt_dec_epilogue(yB[da][0], bi[r], sc[r], sf[r], actp); e.y = srt_dec_epilogue(yA[da][0], bi[r], sc[r], sf[r], actp);
-                e.z = srt_dec_epilogue(yB[da][1], bi[r], sc[r], sf[r], actp); e.w = srt_dec_epilogue(yA[da][1], bi[r], sc[r], sf[r], actp);
-                *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e;
+                for (int da = 0; da < 2; ++da) {
+                    // output row 2(a0+da)+H, columns 2(b0+db)+px: one float4 = (px0 db0, px1 db0, px0 db1, px1 db1)
+                    float4 e;
+                    e.x = act(yB[da][0], r); e.y = act(yA[da][0], r); e.z = act(yB[da][1], r); e.w = act(yA[da][1], r);
+                    *reinterpret_cast<float4*>(oc + (size_t)(2 * da) * Wo) = e;
+                }
             }
-        }
+        };
+        if (blk_ok) {                                                        // the activation kind is workgroup-uniform: one branch around the whole epilogue
+            if (srt_act_is_plain_elu(actp)) emit([&](float y, int r) { return srt_dec_epilogue_elu(y, bi[r], sc[r], sf[r]); });
+            else if (actp.ue != 0.0f) emit([&](float y, int r) { return srt_dec_epilogue(y, bi[r], sc[r], sf[r], actp); });
+            else emit([&](float y, int r) { return srt_dec_epilogue_lin(y, bi[r], sc[r], sf[r], actp.lin); });
         }
         }                                                                    // units
     };
