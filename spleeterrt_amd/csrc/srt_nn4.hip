@@ -145,7 +145,11 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // = 21 points (xi 28..48); waves g and g + 4 share a SIMD, so each SIMD still issues 49 MFMAs per K step.  Two waves per SIMD is
 // the point of the split: measured with one wave per SIMD holding all 49 accumulators (196 registers), every instruction issued
 // between two MFMAs of that wave cost 6-7 cycles on top of the MFMA's 32 - transform arithmetic, LDS reads, address SALU all
-// added up: 46 cycles per MFMA.  With a second wave the SIMD issues one wave's MFMAs while the other does its VALU work.
+// added up: 46 cycles per MFMA.  A second wave covers one wave's waits (LDS operands, the barrier, DMA issue) with the other's MFMAs
+// and halves the per-workgroup prologue / epilogue.  The transform arithmetic itself stays visible: the fp32 MFMA runs on the vector
+// ALU it shares with every other VALU instruction (which is why its peak equals the vector peak), so the ~100 transform instructions
+// per SIMD and K step cost ~20 % of the layer, and why this file is compiled without SLP vectorisation (v_pk_add_f32 beside MFMAs
+// measured 11 % slower than the scalar adds it replaces).
 //
 // Lane (kq = lane / 16, l15 = lane % 16) of a wave owns block 16 g + l15 and, in K step k, input channel 4 k + kq: exactly the
 // (k, n) element the 16x16x4 MFMA wants from this lane as its B operand.  So the lane transforms that block's 4 x 4 patch of that
