@@ -344,9 +344,12 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                         WinoFor<l0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
 #pragma unroll
                         for (int r = 0; r < NROW; ++r) read_row(pbuf, r);
-#pragma unroll
-                        for (int r = 0; r < NROW; ++r) rows(r);
+                        // row transforms where the refills first need them (H = 1: quad 1 refills i = 0 of class (1,1): rows 0, 2; quad 2
+                        // i = 1: row 1; quad 4 i = 3: row 3.  H = 0: quad 1 refills i = 0 of class (0,1): rows 0, 1; quad 3 i = 2: row 2)
+                        rows(0); rows(H ? 2 : 1);
                     } else {
+                        if constexpr (q == 1) rows(H ? 1 : 2);
+                        if constexpr (q == 2 && H) rows(3);
                         WinoFor<4 * q - 4, 4 * q>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
                     }
                 }
@@ -425,8 +428,8 @@ int srt_wino_force()               // tuning builds: SRT_TUNE=...,winoforce=1 ru
     return 0;
 #endif
 }
-// workgroups that walk `tpw` units each: up to 4 (measured: 1 -> 4 takes up5 from 1.43 to 1.34 ms, up4 1.24 -> 1.20, up2 1.12 -> 1.10),
-// as long as it divides the units of a (stem, M block) and leaves two workgroups per CU
+// workgroups that walk `tpw` units each: up to 8 (measured: 1 -> 4 takes up5 from 1.43 to 1.34 ms, up4 1.24 -> 1.20, up2 1.12 -> 1.10; 8 another
+// 0.3-0.5 %), as long as it divides the units of a (stem, M block) and leaves two workgroups per CU
 static int wino_tpw(long wgs, long units)
 {
 #ifdef SRT_TUNING
@@ -434,7 +437,7 @@ static int wino_tpw(long wgs, long units)
     if (t > 0 && units % t == 0) return t;
 #endif
     int tpw = 1;
-    while (tpw < 4 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
+    while (tpw < 8 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
     return tpw;
 }
 int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
