@@ -1,5 +1,7 @@
 #!/bin/bash
-# Winograd decoder form (csrc/srt_nn4.hip): parity at oracle sizes (forced for small batches) and per-layer timing against the direct kernels.
+# Winograd decoder form (csrc/srt_nn4.hip), one gpurun call:  bash scripts/gpu_wino.sh <layer mask> "SRT_TUNE=wino=30;SRT_TUNE=wino=30,winoabl=4;..."
+# 1. parity at oracle sizes with the form FORCED on for small batches too (tuning library, SRT_TUNE=wino=<mask>,winoforce=1): every tensor of
+#    test_forward_layers / geometry sweeps against the CPU oracle;  2. per-layer timing of the listed settings against the product library.
 set -u
 OUT=gpurun_out/wino; mkdir -p $OUT; export TMPDIR=/tmp
 export SPLEETERRT_LIB=$PWD/spleeterrt_amd/libspleeterrt_amd_tuning.so
