@@ -44,7 +44,7 @@ LAYER_SYMBOL = {
     "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false, false>",
     "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false, false>", "up2": "srt_dec_wino<4, 16, 1, 0>",
     "up3": "srt_dec_wino<4, 16, 1, 0>", "up4": "srt_dec_wino<4, 16, 1, 0>",
-    "up5": "srt_dec_wino<4, 16, 1, 0>", "up6": "srt_up6_kernel<8, 64, 32>", "up7": "srt_head_kernel4<false>",
+    "up5": "srt_dec_wino<4, 16, 1, 0>", "up6": "srt_up6_kernel<8, 64, 32, false>", "up7": "srt_head_kernel4<false>",
 }
 # Layers that run in Winograd form (csrc/srt_nn4.hip): the MFMAs EXECUTE 49 products per 2x2 input block where the layer's algorithm
 # (LAYER_FLOP, the reference's direct transposed convolution) has 100.  `achieved` stays algorithmic; `executed` is reported beside it.

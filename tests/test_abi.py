@@ -109,7 +109,27 @@ def test_tuning_build_still_compiles():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "spleeterrt_amd", "csrc")
-    for f in ("srt_nn.hip", "srt_nn2.hip", "srt_nn3.hip"):
+    for f in ("srt_nn.hip", "srt_nn2.hip", "srt_nn3.hip", "srt_nn4.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-DSRT_TUNING", "-fsyntax-only", "-Wno-pass-failed",
                             "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, f)], capture_output=True)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
+
+
+def test_bench_kernel_symbols_exist_in_the_library(lib):
+    """bench.py attributes per-layer times and the rocprofv3 PMC summaries to kernel SYMBOLS (LAYER_SYMBOL).  A template signature that
+    changed without the table (it happened once) silently turns `roofline.traffic` into null: every symbol named there must be a
+    kernel of the built library."""
+    import shutil
+    import sys
+    if not shutil.which("nm"):
+        pytest.skip("nm not available")
+    sys.path.insert(0, ROOT)
+    import bench
+    out = subprocess.run(["nm", "-C", lib[1]], capture_output=True, text=True).stdout
+    have = set()
+    for ln in out.splitlines():
+        m = re.search(r"(?:void )?(?:__device_stub__)?(srt_\w+(?:<[^(]*>)?)\(", ln)
+        if m:
+            have.add(m.group(1))
+    missing = {k: v for k, v in bench.LAYER_SYMBOL.items() if v not in have}
+    assert not missing, "bench.LAYER_SYMBOL names kernels the library does not contain: %r" % (missing,)
