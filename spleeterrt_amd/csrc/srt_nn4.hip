@@ -166,13 +166,14 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // All DMA is issued from inline assembly: the compiler's own bookkeeping of LDS-DMA makes every later LDS read wait for vmcnt(0),
 // i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <int BA, int BB, int NI, int ABL = 0, bool EARLYA = false>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
-// EARLYA (SRT_TUNING builds, SRT_TUNE=winovar=1; correct results, NOT yet measured): U slabs in a ring of FOUR, three steps ahead, so that slab k+1 is
+template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
+// ABL = 10 = EARLYA (SRT_TUNING builds, SRT_TUNE=winovar=1; correct results, NOT yet measured): U slabs in a ring of FOUR, three steps ahead, so that slab k+1 is
 // already guaranteed at barrier k and the first two A-operand reads of step k+1 can be issued behind the last quad of step k - the LDS latency both
 // waves of a SIMD otherwise sit out together right after every barrier would then hide under MFMAs.
 __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
+    constexpr bool EARLYA = ABL == 10;
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;                // patch: PH rows of PROW floats per (channel, instance)
@@ -474,7 +475,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         }
 #endif
 #ifdef SRT_TUNING
-        if (wino_tune("winovar=") == 1) { hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 0, true>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return hipGetLastError() == hipSuccess ? 0 : -1; }
+        if (wino_tune("winovar=") == 1) { hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 10>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return hipGetLastError() == hipSuccess ? 0 : -1; }
 #endif
         hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
     } else if (p.H >= 4 && p.W >= 16) {
