@@ -3,7 +3,7 @@
 # library on the same box:   bash scripts/gpu_tune.sh <tag> <f32|f16|f16x2> "SRT_TUNE=decx=20;SRT_TUNE=bm128=1;SRT_TUNE16=1;SRT_TUNE_HEAD=2"
 # Prints one line per setting: ms per 64-tile step and the per-layer kernel times (HIP events).  Keys: csrc/srt_nn2.hip (SRT_TUNE=key=value,...:
 # down1 down2 up4 up5 abl eabl encx decx bm128 occ3 dual), csrc/srt_nn4.hip (wino=<layer mask> winoforce=1 winotpw=<units per workgroup>
-# winoabl=1..5 winovar=1), csrc/srt_nn3.hip (SRT_TUNE16), csrc/srt_nn.hip (SRT_TUNE_UP6, SRT_TUNE_HEAD).
+# winoabl=1..5), csrc/srt_nn3.hip (SRT_TUNE16), csrc/srt_nn.hip (SRT_TUNE_UP6, SRT_TUNE_HEAD).
 set -u
 TAG=${1:-tune}; PREC=${2:-f32}
 OUT=gpurun_out/$TAG

@@ -167,23 +167,18 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
-// ABL = 10 = EARLYA (SRT_TUNING builds, SRT_TUNE=winovar=1; correct results, NOT yet measured): U slabs in a ring of FOUR, three steps ahead, so that slab k+1 is
-// already guaranteed at barrier k and the first two A-operand reads of step k+1 can be issued behind the last quad of step k - the LDS latency both
-// waves of a SIMD otherwise sit out together right after every barrier would then hide under MFMAs.
 __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
-    constexpr bool EARLYA = ABL == 10;
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;                // patch: PH rows of PROW floats per (channel, instance)
     constexpr int PCH = NI * PH * PROW;                                      // floats per channel
     constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4s (4 channels), DMA pieces and floats per patch buffer
     constexpr int PPW = (NPP + 7) / 8;                                       // patch pieces per wave
-    constexpr int NU = EARLYA ? 4 : 3;                                       // U ring
-    __shared__ __attribute__((aligned(16))) float s_all[NU * UBUF + 3 * PBUF];
+    __shared__ __attribute__((aligned(16))) float s_all[3 * UBUF + 3 * PBUF];
     float* s_u = s_all;
-    float* s_p = s_all + NU * UBUF;
+    float* s_p = s_all + 3 * UBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
@@ -224,7 +219,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
     const float* pa; const float* pb;                                        // wave-uniform: channel 0 of the unit's first instance
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NU * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(3 * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
     auto set_dma_unit = [&](int unit) {
         const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
 #pragma unroll
@@ -295,10 +290,6 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
             for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
 #pragma unroll
             for (int i = 0; i < 2; ++i) dma_u(min(1, nk - 1), 1, i);
-            if constexpr (EARLYA) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) dma_u(min(2, nk - 1), 2, i);
-            }
 #pragma unroll
             for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
 #pragma unroll
@@ -319,20 +310,16 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
         int slot = 0;                                                        // k % 3: U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+3 goes to `slot`
-        float4 ea0, ea1;                                                     // EARLYA: the first two A quads of the coming step
-        if constexpr (EARLYA) { ea0 = *reinterpret_cast<const float4*>(s_u + aoff + X0); ea1 = *reinterpret_cast<const float4*>(s_u + aoff + X0 + 4); }
         for (int k = 0; k < nk; ++k) {
             // vmcnt(2 + PPW): everything older than this wave's pieces of U slab k+1 and patch k+2 (issued in step k-1) has landed - its
             // pieces of U slab k and of patch k+1.  After the barrier so have everyone's, and every wave is done with step k-1: U buffer
             // (k+2)%3 and patch slot k%3 are free.
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | (2 + PPW)); __syncthreads(); }
-            const int kd = min(k + (EARLYA ? 3 : 2), nk - 1), kp = min(k + 3, nk - 1);      // (past the end: refill with the last slab / patch, unused)
-            const int ubn = EARLYA ? ((k + 3) & 3) : (slot == 0 ? 2 : slot - 1);      // (k + 2) % 3; EARLYA: slab k+3 -> buffer (k + 3) % 4
-            const float* ub = s_u + (EARLYA ? (k & 3) : slot) * UBUF + aoff + X0;
+            const int kd = min(k + 2, nk - 1), kp = min(k + 3, nk - 1);      // (past the end: refill with the last slab / patch, unused)
+            const int ubn = slot == 0 ? 2 : slot - 1;                        // (k + 2) % 3
+            const float* ub = s_u + slot * UBUF + aoff + X0;
             const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
-            float4 a0, a1;
-            if constexpr (EARLYA) { a0 = ea0; a1 = ea1; }
-            else { a0 = *reinterpret_cast<const float4*>(ub); a1 = *reinterpret_cast<const float4*>(ub + 4); }
+            float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
             __builtin_amdgcn_sched_barrier(0);
             WinoFor<0, NQ>::run([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -368,10 +355,6 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                 }
                 __builtin_amdgcn_sched_barrier(0);                           // quads stay in order: bounded live ranges, no accumulator copies
             });
-            if constexpr (EARLYA) {                                          // slab k+1 landed before barrier k (see the template comment)
-                const float* un = s_u + ((k + 1) & 3) * UBUF + aoff + X0;
-                ea0 = *reinterpret_cast<const float4*>(un); ea1 = *reinterpret_cast<const float4*>(un + 4);
-            }
             slot = slot == 2 ? 0 : slot + 1;
         }
 
@@ -473,9 +456,6 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         }
-#endif
-#ifdef SRT_TUNING
-        if (wino_tune("winovar=") == 1) { hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 10>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return hipGetLastError() == hipSuccess ? 0 : -1; }
 #endif
         hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
     } else if (p.H >= 4 && p.W >= 16) {
