@@ -37,20 +37,19 @@ for i, (ci, co) in enumerate(_dec):
     LAYER_FLOP["up%d" % (i + 1)] = 2 * co * ci * 25 * (T >> (6 - i)) * (F >> (6 - i))
 LAYER_FLOP["up7"] = 2 * 2 * 16 * T * F
 assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
-# kernel symbol (as rocprofv3 prints it) that runs each layer at T=256, F=1024; layers sharing a symbol have equal FLOPs
-LAYER_SYMBOL = {
-    "down1": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false, false>", "down2": "srt_enc_mfma2<32, 1, 32, 2, 4, 1, 2, false, 0, false, false>",
-    "down3": "srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, 0, false, false>", "down4": "srt_enc_mfma2<128, 2, 32, 2, 4, 1, 2, false, 0, false, false>",
-    "down5": "srt_enc_mfma2<128, 2, 32, 1, 8, 1, 2, false, 0, false, false>", "down6": "srt_enc_mfma2<64, 2, 16, 1, 2, 4, 4, false, 0, false, false>",
-    "up1": "srt_dec_mfma2<64, 2, 16, 1, 2, 2, 4, false, 0, false, false>", "up2": "srt_dec_wino<4, 16, 1, 0>",
-    "up3": "srt_dec_wino<4, 16, 1, 0>", "up4": "srt_dec_wino<4, 16, 1, 0>",
-    "up5": "srt_dec_wino<4, 16, 1, 0>", "up6": "srt_up6_kernel<8, 64, 32, false>", "up7": "srt_head_kernel4<false>",
-}
-# Layers that run in Winograd form (csrc/srt_nn4.hip): the MFMAs EXECUTE 49 products per 2x2 input block where the layer's algorithm
-# (LAYER_FLOP, the reference's direct transposed convolution) has 100.  `achieved` stays algorithmic; `executed` is reported beside it.
+# Which kernel ran each layer is NOT assumed here: the engine reports the symbol of every timed launch (srtGetTimingKernels).
+# Layers that ran in Winograd form (csrc/srt_nn4.hip) EXECUTE 49 MFMA products per 2x2 input block where the layer's algorithm
+# (LAYER_FLOP, the reference's direct transposed convolution) has 100: the roofline fraction is computed on the EXECUTED FLOPs (it can
+# never exceed 1); the algorithmic rate and the 100/49 speed-up are reported beside it.
 WINO_EXECUTED_FRACTION = 0.49
+
+
+def executed_fraction(symbol):
+    return WINO_EXECUTED_FRACTION if "wino" in symbol else 1.0
+
+
 # written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")]
 N_SIMD = 1024                               # 256 CUs x 4 SIMDs: SQ_VALU_MFMA_BUSY_CYCLES is summed over them
 
 
@@ -164,16 +163,15 @@ def main():
     import torch.distributed as dist
     import spleeterrt_amd as srt
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from spleeterrt_amd import stream as srt_stream
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+    # under torch.distributed.run the process group is joined at ANY world size (nccl == RCCL on ROCm): a world of one still loads
+    # RCCL and runs the broadcast / barrier / all-reduce below, so the N > 1 code path is exercised wherever the bench runs
+    rank, world, dist_on = srt_stream.init_distributed(dev)
 
     eng = srt.Engine(F=F, T=T, stem_modes=tuple(int(c) for c in a.stem_modes), oob_weights=(0.25, 0.0, 0.25, 0.25), variant=srt.VARIANT_VST,
                      max_tiles=a.tiles, impl=srt.IMPL_NAIVE if a.impl == "naive" else srt.IMPL_MFMA, device=dev,
@@ -181,7 +179,7 @@ def main():
     # weights: rank 0 creates them, one RCCL broadcast per blob (the only collective on this path)
     for s in range(STEMS):
         w = synth_weights(s, dev) if rank == 0 else torch.empty(9822725, device=dev)
-        if world > 1:
+        if dist_on:
             dist.broadcast(w, 0)
         eng.set_coeff(s, w)
     n = a.tiles * T * HOP
@@ -192,7 +190,7 @@ def main():
     out = torch.empty((STEMS, 2, eng.L.srtIstftLength(rows)), device=dev)
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,8 +212,9 @@ def main():
     sync()
     dt_ev = time.perf_counter() - t1
     tim = eng.get_timing()
+    kern = eng.get_timing_kernels()                           # [(launch name, kernel symbol the engine actually launched)]
     eng.set_timing(False)
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -234,20 +233,22 @@ def main():
         nn_flop = FLOP_PER_PIXEL * T * F * inst
         # dominant kernel = the kernel SYMBOL with the largest share of the step (what tops rocprofv3 --stats);
         # achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the engine's stream)
+        layer_kernel = {}
+        for name, sym in kern:
+            assert layer_kernel.setdefault(name, sym) == sym, "launch %s ran on two kernels: %s / %s" % (name, layer_kernel[name], sym)
         sym_ms, sym_flop, sym_n = {}, {}, {}
         for k in avg:
-            if k in LAYER_FLOP and (a.impl == "mfma" and a.tiles == TILES and a.precision == "f32"):
-                sy = LAYER_SYMBOL[k]
-            else:
-                sy = k
             if k in LAYER_FLOP:
+                sy = layer_kernel.get(k, k)
                 sym_ms[sy] = sym_ms.get(sy, 0.0) + avg[k]
                 sym_flop[sy] = sym_flop.get(sy, 0.0) + LAYER_FLOP[k] * inst
                 sym_n[sy] = sym_n.get(sy, 0) + 1
         dom = max(sym_ms, key=lambda k: sym_ms[k])
         dom_ms = sym_ms[dom] / sym_n[dom]
         dom_flop = sym_flop[dom] / sym_n[dom]
-        dom_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
+        dom_alg_tflops = dom_flop / (dom_ms * 1e-3) / 1e12    # algorithmic (the reference's direct convolution)
+        dom_exec = executed_fraction(dom)
+        dom_tflops = dom_alg_tflops * dom_exec                # what the matrix pipe executes: the roofline figure
         traffic = mfma_busy = pmc_file = None
         def _norm(sym):                                     # kernel symbol without its trailing mode flags (they grow with the code)
             return ",".join(sym.split(",")[:8])
@@ -278,19 +279,21 @@ def main():
                                    "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, frames_step, frames_step * HOP / FS),
                        "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
                        "impl": a.impl, "precision": a.precision},
+            "distributed": ({"backend": dist.get_backend() + " (RCCL)", "world": dist.get_world_size(),
+                             "collectives": "%d weight-blob broadcasts at start-up; barrier + max-all-reduce around the timed region" % STEMS}
+                            if dist_on else None),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, %s)" % pmc_file,
                          "hbm_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "mfma_busy_frac": mfma_busy,
                          "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the launch at the clock the chip held, GRBM_GUI_ACTIVE/8); frac is against the 2.4 GHz peak",
-                         "flop_per_launch": dom_flop, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],
-                         **({"executed": {"flop_per_launch": dom_flop * WINO_EXECUTED_FRACTION,
-                                          "achieved": dom_tflops * WINO_EXECUTED_FRACTION, "unit": "TFLOP/s",
-                                          "frac": dom_tflops * WINO_EXECUTED_FRACTION / PEAK_F32_MFMA_TFLOPS,
-                                          "note": "Winograd F(2,3)/F(2,2) form: the kernel issues 49 MFMA products per 2x2 input block where the direct "
-                                                  "transposed convolution counted in `achieved` has 100; `frac` above can therefore exceed 1, this one cannot"}}
-                            if "wino" in dom else {}),
+                         "flop_per_launch": dom_flop * dom_exec, "avg_ms_per_launch": dom_ms, "launches_per_step": sym_n[dom],
+                         "layers": sorted(k for k in avg if layer_kernel.get(k) == dom),
+                         "kernel_source": "srtGetTimingKernels (the symbol the engine launched in this run)",
+                         "note": "achieved / frac / flop_per_launch count the MFMA products the kernel EXECUTES; for a Winograd-form kernel that is 0.49 of the "
+                                 "layer's algorithmic FLOPs (algorithmic_* below), so frac cannot exceed 1",
+                         "algorithmic_flop_per_launch": dom_flop, "algorithmic_tflops": dom_alg_tflops, "algorithmic_speedup": 1.0 / dom_exec,
                          "share_of_step": sym_ms[dom] / (dt_ev / a.steps * 1e3),
                          # the whole path against the MFMA roofline: algorithmic network FLOP of one step / wall time of one step
                          "step": {"achieved": nn_flop / (step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -303,7 +306,10 @@ def main():
                                   "frac": kb * 1024.0 * rows / (avg[name] * 1e-3) / 8e12, "algorithmic_kb_per_frame": kb}
                            for name, kb in (("stft", 48.8), ("istft", 32.8 + STEMS * 16.0)) if name in avg},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
-            "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},
+            "layer_kernels": {k: layer_kernel[k] for k in sorted(layer_kernel)},
+            "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},     # algorithmic
+            "layer_executed_frac": {k: round(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k)) / (avg[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                                    for k in avg if k in LAYER_FLOP},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
@@ -312,7 +318,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (ex,)}
         print(json.dumps(res))
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

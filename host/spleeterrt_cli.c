@@ -6,7 +6,9 @@
  *
  * Mirrors Executable/main.c:
  *   argument order, clamps and messages' meaning        main.c:704-748   (spawnNthreads is accepted and ignored:
- *                                                                          the GPU batches every tile of the file)
+ *                                                                          the GPU batches the tiles of the file)
+ *   any file length: the reference walks the tiles one at a time (main.c:455-495); here the engine holds at most
+ *   $SPLEETERRT_MAX_TILES (default 64) tiles and srtSeparateCliHost walks longer files chunk by chunk
  *   4096-sample pre-shift, 4096*ceil(n/4096)+8192 pad   main.c:762-767
  *   mono input duplicated to both channels              main.c:768-769
  *   stems <= 2 -> <name>_Vocal.wav, <name>_Accompaniment.wav; else + <name>_Drum.wav      main.c:812-843, 894-965
@@ -43,7 +45,10 @@ static size_t read_wav(const char *path, float **pcm, unsigned *channels, unsign
     FILE *f = fopen(path, "rb");
     if (!f) { fprintf(stderr, "cannot open %s\n", path); return 0; }
     unsigned char h[12];
-    if (fread(h, 1, 12, f) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) {
+    if (fread(h, 1, 12, f) == 12 && (!memcmp(h, "RF64", 4) || !memcmp(h, "BW64", 4))) {
+        fprintf(stderr, "%s: RF64/BW64 (a WAVE file beyond 4 GiB) is not supported: the reference's float32 RIFF outputs could not hold the result; split the input\n", path); fclose(f); return 0;
+    }
+    if (memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) {
         fprintf(stderr, "%s: not a RIFF/WAVE file (FLAC/MP3 decoding is outside this harness)\n", path); fclose(f); return 0;
     }
     unsigned fmt = 0, ch = 0, bits = 0, sr = 0;
@@ -63,6 +68,7 @@ static size_t read_wav(const char *path, float **pcm, unsigned *channels, unsign
             const unsigned bps = bits / 8;
             const int ok = (fmt == 1 && (bps >= 1 && bps <= 4)) || (fmt == 3 && bps == 4);
             if (!ok || ch < 1 || ch > 2) { fprintf(stderr, "%s: unsupported WAVE encoding (format %u, %u bits, %u channels)\n", path, fmt, bits, ch); fclose(f); return 0; }
+            if (sz == 0xFFFFFFFFu) { fprintf(stderr, "%s: data chunk of unknown length (streamed / > 4 GiB WAVE) is not supported; rewrite the file with a sized data chunk\n", path); fclose(f); return 0; }
             const size_t frames = (size_t)sz / ((size_t)bps * ch), ns = frames * ch;
             unsigned char *raw = (unsigned char *)malloc((size_t)sz ? (size_t)sz : 1);
             float *out = (float *)malloc((ns ? ns : 1) * sizeof(float));
@@ -151,18 +157,20 @@ int main(int argc, char **argv)
     cfg.F = (int)F; cfg.T = (int)T; cfg.n_stems = 2;
     cfg.stem_mode[0] = 1; cfg.stem_mode[1] = 0;                        /* net[0] drum: ELU; net[1] vocal: LeakyReLU/ReLU  (main.c:782,858,911) */
     cfg.oob_weight[0] = cfg.oob_weight[1] = 0.1f;                      /* unaffectedWeight, main.c:773 */
-    cfg.variant = SRT_VARIANT_EXE; cfg.max_tiles = (int)((rows + T - 1) / T); cfg.impl = SRT_IMPL_MFMA; cfg.precision = SRT_PREC_F32;
+    /* Engine capacity: the whole file when it is short, otherwise a fixed number of tiles (activations of every tile of a chunk live in
+     * HBM at once: ~0.1 GB per tile at 512 x 1024); srtSeparateCliHost then walks the file chunk by chunk, so any length works. */
+    const char *mt = getenv("SPLEETERRT_MAX_TILES");
+    size_t cap = mt && atoi(mt) > 0 ? (size_t)atoi(mt) : 64, ntiles = (rows + T - 1) / T;
+    cfg.variant = SRT_VARIANT_EXE; cfg.max_tiles = (int)(ntiles < cap ? ntiles : cap); cfg.impl = SRT_IMPL_MFMA; cfg.precision = SRT_PREC_F32;
     srt_engine *e = 0;
     if (srtCreate(&cfg, 0, &e)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
     if (srtSetCoeffFp16Host(e, 0, halfs) || srtSetCoeffFp16Host(e, 1, halfs + nhalf)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
     free(halfs);
-    /* The whole file is one resident batch (every tile of both sub-networks lives in HBM at once: ~0.1 GB per tile at 512 x 1024,
-     * i.e. about an hour of audio per 100 GB); srtCreate reports a clean error when the file is too long for the device. */
     float *out = (float *)malloc((size_t)stems * 2 * len * sizeof(float));
     if (!out) { fprintf(stderr, "out of host memory (%zu output samples)\n", (size_t)stems * 2 * len); return -1; }
     t0 = now();
     if (srtSeparateCliHost(e, inL, inR, finalSize, stems, out)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
-    printf("Inference neural networks on the GPU takes %1.14lf sec (%d tiles of %zu x %zu, %d outputs)\n", now() - t0, cfg.max_tiles, T, F, stems);
+    printf("Inference neural networks on the GPU takes %1.14lf sec (%zu tiles of %zu x %zu in chunks of %d, %d outputs)\n", now() - t0, ntiles, T, F, cfg.max_tiles, stems);
     srtDestroy(e);
 
     static const char *names2[] = { "Vocal", "Accompaniment" }, *names3[] = { "Drum", "Vocal", "Accompaniment" };

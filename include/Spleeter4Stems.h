@@ -15,7 +15,8 @@
  * Per hop the GPU runs one forward and four masked inverse 4096-point FFTs + 50 % overlap-add on a dedicated stream; every
  * timeStep hops the four U-Nets run on a second stream, overlapped with the following hops exactly like the reference's
  * four network threads, and are joined one batch later (Spleeter4Stems.c:351-371).
- * Failures print to stderr and abort(); there is no CPU fallback.
+ * Failures never abort() and never fall back to a CPU path: the reason goes to stderr and srtLastError(), the instance is
+ * marked failed and from then on returns zeros / silence with the reference's sample accounting (SPLEETERRT_ABORT_ON_ERROR=1 aborts instead).
  */
 #ifndef SPLEETERRT_AMD_SPLEETER4STEMS_H
 #define SPLEETERRT_AMD_SPLEETER4STEMS_H

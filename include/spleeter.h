@@ -7,8 +7,11 @@
  *   - `coeff` holds getCoeffSize() bytes laid out as spleeterCoeff; it is copied to HBM at init
  *     (the reference borrows it, spleeter.c:129 — a caller that keeps it alive is still correct);
  *   - x and y are HOST pointers to [2][height][width] floats; y may alias the getMaskPtr() buffer (main.c:453,472);
- *   - all functions return void.  Where the reference has undefined behaviour on failure, this library prints
- *     the reason to stderr and abort()s — there is no CPU fallback.
+ *   - all functions return void.  Where the reference has undefined behaviour on failure (no GPU, out of memory, a HIP error),
+ *     this library prints the reason to stderr, keeps it readable through srtLastError(), marks the instance failed and from then
+ *     on writes ZERO masks — it never abort()s the host and never falls back to a CPU path (SPLEETERRT_ABORT_ON_ERROR=1 aborts instead).
+ *   - initSpleeter also pre-warms the device side (workspace allocation, hipGraph capture), so the first processSpleeter costs what
+ *     every later one does.
  * One instance is not re-entrant; distinct instances may be used from distinct threads (main.c:296-330).
  * Flavour: environment variable SPLEETERRT_VARIANT = "exe" (default: LUT sigmoid, ELU clamp) or "vst".
  * For throughput use the batched, HBM-resident API in spleeterrt_amd.h; this header is the compatibility surface.

@@ -51,6 +51,12 @@ typedef struct srt_config {
     int   ratio_mask;               /* 0 (reference behaviour: raw sigmoid masks) | 1: srtSeparate / srtSeparateEx / srtSeparateHostStream normalise
                                      * m_s^2 / sum_j m_j^2 across stems (README.MD:82-85).  The CLI flows (srtSeparateCli*) reject it: their
                                      * sub-networks run one after the other on different inputs, so there is no stem axis to normalise over. */
+    int   batch_invariant;          /* 0 (default): the fastest kernel per launch - small launches (<= 16 instances) cut the deep layers' K loops
+                                     * into slices (split-K) and keep the direct decoder kernels, larger ones run up2..up5 in Winograd form, so the
+                                     * same tile can differ in the last bits (<= 2e-5 on masks) with the batch it is evaluated in.
+                                     * 1: kernel choice by layer geometry only, no split-K: a tile's result is bit-identical whatever the batch
+                                     * size, tile slot, stem range or rank partition (what the reference's CPU path guarantees); small batches
+                                     * run slower.  The environment variable SPLEETERRT_BATCH_INVARIANT=1 forces it for every engine. */
 } srt_config;
 
 SRT_API int  srtCreate(const srt_config *cfg, void *stream, srt_engine **out);
@@ -111,11 +117,21 @@ SRT_API int  srtSeparateCliHost(srt_engine *e, const float *h_L, const float *h_
  * tuples, least recently used evicted).  Needs an explicit stream (the legacy null stream cannot be captured: the engine then
  * keeps launching eagerly).  Results are identical either way.  Off by default. */
 SRT_API int  srtSetGraphMode(srt_engine *e, int enable);
+/* Everything the first srtForward(e, d_mag, ntiles, d_masks) would otherwise do lazily - the split-K workspace allocation and, in
+ * graph mode, the capture + instantiation of the launch sequence for exactly this argument tuple - done NOW and synchronised, so
+ * that the first real call (on a real-time audio thread) is a plain graph launch.  Runs the networks once: d_masks is overwritten.
+ * The drop-in layers call it from their Init functions for every buffer pair they will use. */
+SRT_API int  srtPrepareForward(srt_engine *e, const float *d_mag, int ntiles, float *d_masks);
+/* free the grow-only device staging of the host-buffer entry points (srtSeparateHostStream*, srtSeparateCliHost); the next such call re-allocates */
+SRT_API int  srtReleaseStaging(srt_engine *e);
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */
 SRT_API int  srtSetTiming(srt_engine *e, int enable);                    /* record HIP events around every launch of the next calls */
 SRT_API int  srtGetTiming(srt_engine *e, char *names, size_t names_bytes, float *ms, int max_entries); /* returns count; syncs the stream */
+/* which kernel ran each of those launches (same order), ';'-separated, named as rocprofv3 names kernels ("srt_dec_wino<4, 16, 1, 0>"):
+ * the dispatch depends on batch size and geometry, so tests and bench.py read it from here instead of assuming it.  Returns the count. */
+SRT_API int  srtGetTimingKernels(srt_engine *e, char *kernels, size_t kernels_bytes);
 
 #ifdef __cplusplus
 }

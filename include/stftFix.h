@@ -10,7 +10,8 @@
  *   - stft() calloc()s four planes of rows*4096 floats (row stride FFTSIZE, bins 2049..4095 zero) that the caller
  *     free()s (main.c:786-789); istft() calloc()s the two output channels.  HOST pointers throughout;
  *   - unlike the reference's multi-threaded istft (stftFix.c:537-538) the input planes are left untouched.
- * Failures print to stderr and abort(); there is no CPU fallback.
+ * Failures never abort() and never fall back to a CPU path: the reason goes to stderr and srtLastError(), the instance is
+ * marked failed and from then on returns zeros / silence with the reference's sample accounting (SPLEETERRT_ABORT_ON_ERROR=1 aborts instead).
  */
 #ifndef _STFT_H_
 #define _STFT_H_

@@ -57,16 +57,12 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
     from spleeterrt_amd import stream
     from bench import synth_weights
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("stream_c4.py needs a GPU: the HIP library has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dist_on = stream.init_distributed(dev)          # joins the nccl (RCCL) group under a launcher at any world size, 1 included
 
     n_audio = int(round(minutes * 60 * FS))
     n = 4096 * ((n_audio + 4095) // 4096) + 8192                  # the CLI's padding (main.c:762-767): 60 min -> 158 769 152
@@ -79,7 +75,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
     t_b0 = time.perf_counter()
     for s in range(STEMS):                                          # the one collective of the path
         w = synth_weights(s, dev) if rank == 0 else torch.empty(9822725, device=dev)
-        if world > 1:
+        if dist_on:
             dist.broadcast(w, 0)
         eng.set_coeff(s, w)
     torch.cuda.synchronize()
@@ -100,7 +96,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     def one_pass():
@@ -114,7 +110,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
         one_pass()
     sync()
     dt = (time.perf_counter() - t0) / repeats
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -154,6 +150,7 @@ def run(minutes=60.0, max_tiles=64, gather=True, check_seams=True, precision="f3
             "bytes_h2d": 2 * 4 * n, "bytes_d2h": STEMS * 2 * 4 * (rows * HOP + 3072),
             "weight_setup_s": t_bcast, "collect_on_rank0_s": t_gather if gather else None,
             "collective": "broadcast of %d weight blobs (39.29 MB each) only" % STEMS,
+            "process_group": (dist.get_backend() if dist_on else None),
         }
         if full is not None:
             res["checksum"] = {"sum": [float(full[s].astype(np.float64).sum()) for s in range(STEMS)],

@@ -4,7 +4,7 @@
 
 --tuning builds a SECOND library, libspleeterrt_amd_tuning.so, with -DSRT_TUNING: the alternative tile shapes, kernel
 variants and ablation builds measured for DESIGN.md (selected at run time with SRT_TUNE=key=value,...).  It is loaded only
-when SPLEETERRT_LIB points at it (scripts/tune.sh); the product library never contains those variants.
+when SPLEETERRT_LIB points at it (scripts/gpu_tune.sh); the product library never contains those variants.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the GPU box.
 """

@@ -19,7 +19,7 @@ class EngineError(RuntimeError):
 class _Config(C.Structure):
     _fields_ = [("F", C.c_int), ("T", C.c_int), ("n_stems", C.c_int), ("stem_mode", C.c_int * MAX_STEMS),
                 ("oob_weight", C.c_float * MAX_STEMS), ("variant", C.c_int), ("max_tiles", C.c_int), ("impl", C.c_int), ("precision", C.c_int),
-                ("ratio_mask", C.c_int)]
+                ("ratio_mask", C.c_int), ("batch_invariant", C.c_int)]
 
 
 _lib = None
@@ -30,7 +30,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.environ.get("SPLEETERRT_LIB") or SO           # SPLEETERRT_LIB: the -DSRT_TUNING measurement build (scripts/tune.sh)
+    so = os.environ.get("SPLEETERRT_LIB") or SO           # SPLEETERRT_LIB: the -DSRT_TUNING measurement build (scripts/gpu_tune.sh)
     if not os.path.exists(so):
         raise EngineError("%s not built: run `python -m spleeterrt_amd.build` (needs hipcc); no CPU fallback exists" % so)
     import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
@@ -61,8 +61,11 @@ def load_library():
     L.srtSeparateEx.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
     L.srtCopyTensor.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
     L.srtSetGraphMode.argtypes = [vp, C.c_int]
+    L.srtPrepareForward.argtypes = [vp, f32p, C.c_int, f32p]
+    L.srtReleaseStaging.argtypes = [vp]
     L.srtSetTiming.argtypes = [vp, C.c_int]
     L.srtGetTiming.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
+    L.srtGetTimingKernels.argtypes = [vp, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -75,7 +78,7 @@ class Engine:
     """One engine per (device, stream): nstems sub-networks evaluated over batches of T x F spectrogram tiles."""
 
     def __init__(self, F=1024, T=256, stem_modes=(1, 1, 1, 1), oob_weights=None, variant=VARIANT_EXE, max_tiles=1,
-                 impl=IMPL_MFMA, device=None, precision=PREC_F32, ratio_mask=False):
+                 impl=IMPL_MFMA, device=None, precision=PREC_F32, ratio_mask=False, batch_invariant=False):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: spleeterrt_amd has no CPU path")
@@ -88,6 +91,7 @@ class Engine:
         cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.impl = F, T, self.S, variant, max_tiles, impl
         cfg.precision = precision
         cfg.ratio_mask = int(bool(ratio_mask))
+        cfg.batch_invariant = int(bool(batch_invariant))
         for i, m in enumerate(stem_modes):
             cfg.stem_mode[i] = int(m)
             cfg.oob_weight[i] = 0.1 if oob_weights is None else float(oob_weights[i])
@@ -190,6 +194,17 @@ class Engine:
         self._chk(self.L.srtSeparateCli(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, stems, _ptr(out)))
         return out
 
+    def separate_cli_host(self, L, R, stems):
+        """the CLI flow from host buffers (numpy float32), any length: one resident batch when the file fits max_tiles tiles, otherwise
+        chunk by chunk (srtSeparateCliHost) -> numpy [stems,2,len]"""
+        import numpy as np
+        L = np.ascontiguousarray(L, np.float32)
+        R = np.ascontiguousarray(R, np.float32)
+        assert L.size == R.size
+        out = np.empty((stems, 2, self.L.srtIstftLength(self.L.srtStftRows(L.size))), np.float32)
+        self._chk(self.L.srtSeparateCliHost(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), L.size, stems, C.c_void_p(out.ctypes.data)))
+        return out
+
     def separate_host_stream(self, L, R, frames=None, rows=None, out=None, pinned=False):
         """host PCM of any length -> host stems [S,2,rows*1024+3072]; chunks of max_tiles tiles with the PCIe copies
         overlapped with compute (srtSeparateHostStreamEx).  L, R, out: contiguous float32 numpy arrays or CPU torch
@@ -247,6 +262,13 @@ class Engine:
         """replay srtForward / srtSeparate as captured hipGraphs when called again with the same tensors (needs a non-default stream)"""
         self._chk(self.L.srtSetGraphMode(self.h, int(on)))
 
+    def prepare_forward(self, mag, masks):
+        """allocate / capture everything forward(mag, masks) would do lazily (runs the networks once into masks)"""
+        self._chk(self.L.srtPrepareForward(self.h, _ptr(mag), mag.shape[0], _ptr(masks)))
+
+    def release_staging(self):
+        self._chk(self.L.srtReleaseStaging(self.h))
+
     def set_timing(self, on=True):
         self._chk(self.L.srtSetTiming(self.h, int(on)))
 
@@ -256,3 +278,11 @@ class Engine:
         n = self._chk(self.L.srtGetTiming(self.h, names, len(names), ms, max_entries))
         nm = names.value.decode().split(",")[:n]
         return list(zip(nm, list(ms[:n])))
+
+    def get_timing_kernels(self, max_entries=65536):
+        """[(launch name, kernel symbol that ran it)] for the launches recorded since set_timing(True)"""
+        tim = self.get_timing(max_entries)
+        buf = C.create_string_buffer(len(tim) * 160 + 16)
+        n = self._chk(self.L.srtGetTimingKernels(self.h, buf, len(buf)))
+        ks = buf.value.decode().split(";")[:n]
+        return [(name, k) for (name, _), k in zip(tim, ks)]

@@ -75,6 +75,9 @@ void initSpleeter(struct _spleeter* nn, size_t width, size_t height, int stemMod
     srtSetGraphMode(nn->eng, 1);                              // every processSpleeter call repeats the same launch sequence on d_x / d_y
     if (!hip_ok(hipMalloc((void**)&nn->d_x, nn->hw2 * sizeof(float)), "initSpleeter")) { nn->d_x = nullptr; return; }
     if (!hip_ok(hipMalloc((void**)&nn->d_y, nn->hw2 * sizeof(float)), "initSpleeter")) { nn->d_y = nullptr; return; }
+    // pre-warm here, not in the first processSpleeter (which may be a real-time thread): workspace allocation + graph capture / instantiate
+    if (!hip_ok(hipMemsetAsync(nn->d_x, 0, nn->hw2 * sizeof(float), nn->stream), "initSpleeter")) return;
+    if (srtPrepareForward(nn->eng, nn->d_x, 1, nn->d_y)) { compat_fail("initSpleeter(prepare)", nullptr); return; }
     nn->failed = 0;
 }
 

@@ -264,7 +264,7 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
     const int fpb = p.rows_total >= 4096 ? STFT_FPB : (p.rows_total >= 1024 ? 2 : 1);
     const int blocks = (p.rows_total + fpb - 1) / fpb;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
+    SRT_LAUNCH(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -383,7 +383,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     if (G < gmin) G = gmin;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
-    hipLaunchKernelGGL(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    SRT_LAUNCH(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) srt_residual_kernel(const SrtResidualPara
 int srt_launch_residual(const SrtResidualParams& p, hipStream_t s)
 {
     if (p.rows <= 0) return 0;
-    hipLaunchKernelGGL(srt_residual_kernel, dim3(p.rows, 2), dim3(256), 0, s, p);
+    SRT_LAUNCH(srt_residual_kernel, dim3(p.rows, 2), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) srt_time_residual_kernel(const float* aL,
 int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s)
 {
     if (!nb) return 0;
-    hipLaunchKernelGGL(srt_time_residual_kernel, dim3((unsigned)((nb + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out);
+    SRT_LAUNCH(srt_time_residual_kernel, dim3((unsigned)((nb + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) srt_carry_kernel(float* out, size_t plane
 int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, float* carry, int first, int last, hipStream_t s)
 {
     if (first && last) return 0;
-    hipLaunchKernelGGL(srt_carry_kernel, dim3((SRT_FFT - SRT_HOP) / 256, nplanes), dim3(256), 0, s, out, plane_len, tail, carry, first, last);
+    SRT_LAUNCH(srt_carry_kernel, dim3((SRT_FFT - SRT_HOP) / 256, nplanes), dim3(256), 0, s, out, plane_len, tail, carry, first, last);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(256) srt_ratio_mask_kernel(float* masks, int n
 int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s)
 {
     if (!count || nstems < 1) return 0;
-    hipLaunchKernelGGL(srt_ratio_mask_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, masks, nstems, count);
+    SRT_LAUNCH(srt_ratio_mask_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, masks, nstems, count);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -583,8 +583,8 @@ __global__ void __launch_bounds__(256) srt_stream_forward_kernel(const SrtStream
 
 int srt_launch_stream_hop(const SrtStreamHop& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_stream_inverse_kernel, dim3(4), dim3(256), 0, s, p);     // reads the delayed row ...
+    SRT_LAUNCH(srt_stream_inverse_kernel, dim3(4), dim3(256), 0, s, p);     // reads the delayed row ...
     if (hipGetLastError() != hipSuccess) return -1;
-    hipLaunchKernelGGL(srt_stream_forward_kernel, dim3(1), dim3(256), 0, s, p);     // ... before the current frame overwrites it
+    SRT_LAUNCH(srt_stream_forward_kernel, dim3(1), dim3(256), 0, s, p);     // ... before the current frame overwrites it
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

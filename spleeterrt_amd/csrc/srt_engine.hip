@@ -15,6 +15,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <cxxabi.h>
 
 static thread_local char g_err[512] = "";
 int srt_set_error(int code, const char* fmt, const char* detail)      // shared with the drop-in layers (srt_compat.hip, srt_stream.hip)
@@ -23,6 +24,12 @@ int srt_set_error(int code, const char* fmt, const char* detail)      // shared 
     return code;
 }
 static int fail(int code, const char* fmt, const char* detail = "") { return srt_set_error(code, fmt, detail); }
+
+// first kernel the calling thread launched since the last reset (SRT_LAUNCH, srt_internal.h)
+static thread_local const void* g_kfn = nullptr;
+static thread_local const char* g_ktext = nullptr;
+void srt_kernel_note(const void* fn, const char* text) { if (!g_kfn) { g_kfn = fn; g_ktext = text; } }
+void srt_kernel_note_reset() { g_kfn = nullptr; g_ktext = nullptr; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(-2, "HIP error: %s", hipGetErrorString(_e)); } while (0)
 
 static const int ENC_CH[6][2] = { {2, 16}, {16, 32}, {32, 64}, {64, 128}, {128, 256}, {256, 512} };
@@ -46,7 +53,7 @@ static Layout make_layout()
     return lo;
 }
 
-struct TimingEntry { std::string name; hipEvent_t a, b; };
+struct TimingEntry { std::string name; hipEvent_t a, b; const void* kfn; const char* ktext; };
 #define SRT_TIMING_MAX 65536        // launches recorded per srtSetTiming(1) window; later launches run untimed
 
 // Persistent staging of srtSeparateHostStream / srtSeparateCliHost: device double buffers, copy streams and events are
@@ -119,13 +126,14 @@ struct TimerScope {
     srt_engine* e; size_t idx; bool on;
     TimerScope(srt_engine* e_, const char* name) : e(e_), idx(0), on(e_->timing && e_->tlog.size() < SRT_TIMING_MAX) {
         if (!on) return;
-        TimingEntry t; t.name = name;
+        TimingEntry t; t.name = name; t.kfn = nullptr; t.ktext = nullptr;
+        srt_kernel_note_reset();
         if (hipEventCreate(&t.a) != hipSuccess) { on = false; return; }
         if (hipEventCreate(&t.b) != hipSuccess) { hipEventDestroy(t.a); on = false; return; }
         hipEventRecord(t.a, e->stream);
         e->tlog.push_back(t); idx = e->tlog.size() - 1;
     }
-    ~TimerScope() { if (on) hipEventRecord(e->tlog[idx].b, e->stream); }
+    ~TimerScope() { if (on) { hipEventRecord(e->tlog[idx].b, e->stream); e->tlog[idx].kfn = g_kfn; e->tlog[idx].ktext = g_ktext; } }
 };
 
 static void free_staging(srt_engine* e)
@@ -189,7 +197,9 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
     e->preWin = e->postWin = nullptr; e->twiddle = nullptr; e->spec = nullptr; e->spec2 = nullptr; e->mag = e->masks = e->frames = nullptr;
-    e->cfg = *cfg; e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
+    e->cfg = *cfg;
+    { const char* bi = getenv("SPLEETERRT_BATCH_INVARIANT"); if (bi && bi[0] == '1') e->cfg.batch_invariant = 1; }
+    e->stream = (hipStream_t)stream; e->lo = make_layout(); e->timing = false; e->last_ntiles = cfg->max_tiles;
     if (e->lo.total != SRT_COEFF_FLOATS) { delete e; return fail(-4, "internal: weight layout size mismatch"); }
     const size_t S = cfg->n_stems, NT = cfg->max_tiles, HW = (size_t)cfg->T * cfg->F;
 #define EALLOC(ptr, nfloats) do { if (hipMalloc((void**)&(ptr), (nfloats) * sizeof(float)) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); } } while (0)
@@ -314,34 +324,46 @@ int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 // the launchers get a workspace so they can cut those layers' K loops into slices (srt_nn2.hip, split-K).
 static void ensure_ws(srt_engine* e, size_t instances)
 {
-    if (e->ws || instances > 16 || e->cfg.impl != SRT_IMPL_MFMA || e->cfg.precision != SRT_PREC_F32) return;
+    if (e->ws || instances > 16 || e->cfg.batch_invariant || e->cfg.impl != SRT_IMPL_MFMA || e->cfg.precision != SRT_PREC_F32) return;
     const size_t want = (size_t)16 << 20;                  // 64 MiB: 8 slices of the largest split layer at 8 instances
     if (hipMalloc((void**)&e->ws, want * sizeof(float)) == hipSuccess) e->ws_floats = want;
     else { e->ws = nullptr; (void)hipGetLastError(); }
 }
 
-// Run `issue` (a function that only enqueues work on e->stream) through the graph cache when graph mode is on.
+// Run `issue` (a function that only enqueues work on e->stream) through the graph cache when graph mode is on.  `valid` says
+// whether the arguments passed the entry point's checks: an invalid call is issued eagerly (it fails with its own error code and
+// nothing is captured).  Graph mode is switched off for good only when the capture / instantiate API itself fails - a user error
+// such as missing weights leaves it on.  If the caller's stream is already capturing (the caller builds its own graph), the
+// launches simply join that capture.
 template <class F>
-static int run_graphed(srt_engine* e, const GraphKey& key, F&& issue)
+static int run_graphed(srt_engine* e, const GraphKey& key, bool valid, F&& issue)
 {
-    if (!e->graph_mode || e->timing || !e->stream) return issue();      // the legacy null stream cannot be captured
+    if (!e->graph_mode || e->timing || !e->stream || !valid) return issue();      // the legacy null stream cannot be captured
     for (GraphSlot& g : e->gslots)
         if (g.exec && !memcmp(&g.key, &key, sizeof key)) {
             g.used = ++e->gclock;
             HIPCHK(hipGraphLaunch(g.exec, e->stream));
             return 0;
         }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(e->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return issue(); }
+    if (cap != hipStreamCaptureStatusNone) return issue();                 // inside the caller's capture: do not nest one
     if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e->graph_mode = 0; return issue(); }
     const int rc = issue();
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipError_t er = hipStreamEndCapture(e->stream, &graph);
-    if (rc == 0 && er == hipSuccess && graph) er = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (rc || er != hipSuccess || !exec) {                               // capture is not available here: fall back to plain launches for good
+    if (rc) {                                                              // the sequence itself failed (its error text is set): nothing to replay, graph mode stays on
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return rc;
+    }
+    if (er == hipSuccess && graph) er = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (er != hipSuccess || !exec) {                                       // capture is not available here: plain launches from now on
         if (graph) hipGraphDestroy(graph);
         (void)hipGetLastError();
         e->graph_mode = 0;
-        return rc ? rc : issue();
+        return issue();
     }
     GraphSlot* v = &e->gslots[0];
     for (GraphSlot& g : e->gslots) if (!g.exec || g.used < v->used) { v = &g; if (!g.exec) break; }
@@ -367,7 +389,11 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (e->stream) (void)hipStreamIsCapturing(e->stream, &cap);
     if (cap == hipStreamCaptureStatusNone) ensure_ws(e, (size_t)ns * ntiles);      // (no allocation inside a capture: callers pre-allocate)
-    const bool small = e->ws && (size_t)ns * ntiles <= 16;
+    // Kernel choice by launch size: at most 16 instances keep the direct decoder kernels and (when the workspace exists) cut the deep
+    // layers' K loops into slices; larger launches run up2..up5 in Winograd form.  batch_invariant: never split-K (ws stays null) and
+    // the Winograd decoders whenever the layer geometry fits, whatever the batch - the same bits for a tile in any batch.
+    const bool few = (size_t)ns * ntiles <= 16 && !e->cfg.batch_invariant;
+    const bool small = few && e->ws;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
         unsigned elu_mask = 0;
@@ -454,7 +480,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 rc2 = srt_launch_dec_f16(p, e->stream);
             }
             if (e->act16 && i < 5 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for a decoder layer");
-            if (rc2 == 1 && e->wino_u[i] && (!small || srt_wino_force())) rc2 = srt_launch_dec_wino(p, e->wino_u[i] + (size_t)s0 * e->wino_u_stem[i], e->wino_u_stem[i], e->stream);
+            if (rc2 == 1 && e->wino_u[i] && (!few || srt_wino_force())) rc2 = srt_launch_dec_wino(p, e->wino_u[i] + (size_t)s0 * e->wino_u_stem[i], e->wino_u_stem[i], e->stream);
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_dec2(p, e->stream);
             if (rc2 < 0) return fail(-2, "decoder launch failed");
             if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
@@ -478,12 +504,36 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
     if (!e) return fail(-1, "srtForward: null argument");
     if (!e->graph_mode) return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems);
     DeviceScope ds(e->device);
-    if (ntiles >= 1) ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
+    bool valid = d_mag && d_masks && ntiles >= 1 && ntiles <= e->cfg.max_tiles;
+    for (int s = 0; s < e->cfg.n_stems; ++s) valid = valid && e->have_coeff[s];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (e->stream) (void)hipStreamIsCapturing(e->stream, &cap);
+    if (valid && cap == hipStreamCaptureStatusNone) ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
     GraphKey k; memset(&k, 0, sizeof k);
     k.kind = 1; k.p0 = d_mag; k.p2 = d_masks; k.ntiles = ntiles; k.ns = e->cfg.n_stems;
-    const int rc = run_graphed(e, k, [&]() { return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems); });
+    const int rc = run_graphed(e, k, valid, [&]() { return forward_range(e, d_mag, ntiles, d_masks, 0, e->cfg.n_stems); });
     if (!rc) e->last_ntiles = ntiles;
     return rc;
+}
+
+int srtPrepareForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
+{
+    if (!e) return fail(-1, "srtPrepareForward: null argument");
+    DeviceScope ds(e->device);
+    const int rc = srtForward(e, d_mag, ntiles, d_masks);     // allocates the workspace, captures + instantiates (graph mode), runs once
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int srtReleaseStaging(srt_engine* e)
+{
+    if (!e) return fail(-1, "srtReleaseStaging: null argument");
+    DeviceScope ds(e->device);
+    if (e->hs.ready) { hipStreamSynchronize(e->hs.s_in); hipStreamSynchronize(e->hs.s_out); }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    free_staging(e);
+    return 0;
 }
 
 int srtForwardStems(srt_engine* e, const float* d_mag, int ntiles, float* d_masks, int stem0, int nstems)
@@ -571,10 +621,14 @@ int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, s
     if (rows < 1 || ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparate: signal longer than max_tiles * T frames");
     if (!e->graph_mode) return separate_issue(e, d_L, d_R, n, frames, rows, d_out);
     DeviceScope ds(e->device);
-    ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
+    bool valid = d_L && d_R && d_out && frames <= rows;
+    for (int s = 0; s < e->cfg.n_stems; ++s) valid = valid && e->have_coeff[s];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (e->stream) (void)hipStreamIsCapturing(e->stream, &cap);
+    if (valid && cap == hipStreamCaptureStatusNone) ensure_ws(e, (size_t)e->cfg.n_stems * ntiles);
     GraphKey k; memset(&k, 0, sizeof k);
     k.kind = 2; k.p0 = d_L; k.p1 = d_R; k.p2 = d_out; k.n = n; k.frames = frames; k.rows = rows;
-    const int rc = run_graphed(e, k, [&]() { return separate_issue(e, d_L, d_R, n, frames, rows, d_out); });
+    const int rc = run_graphed(e, k, valid, [&]() { return separate_issue(e, d_L, d_R, n, frames, rows, d_out); });
     if (!rc) e->last_ntiles = (int)ntiles;
     return rc;
 }
@@ -608,17 +662,21 @@ static int istft_one(srt_engine* e, const float2* spec, size_t rows, const float
 //   2: vocal = istft(mask1 . S);  accompaniment = input - vocal                                  (time-domain residual)
 //   3: drum = istft(mask0 . S);  R = S - mask0 . S;  vocal = istft(mask1(|R|) . R);  accompaniment = istft(R) - vocal
 // d_out: [stems][2][srtIstftLength(rows)] in the CLI's file order: (Vocal, Accompaniment) or (Drum, Vocal, Accompaniment).
-int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out)
+// Explicit geometry as srtSeparateEx (a tile range of a longer file).  residual_now = false leaves the last, time-domain subtraction
+// to the caller: the chunked pipeline first adds the previous chunk's overlap to every plane (the accompaniment slot then holds
+// the UNsubtracted term: nothing for 2 outputs, istft(R) for 3) and subtracts afterwards (cli_time_residual).
+static int cli_time_residual(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out, size_t len)
 {
-    if (!e || !d_L || !d_R || !d_out) return fail(-1, "srtSeparateCli: null argument");
-    DeviceScope ds(e->device);
-    if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
-    if (e->cfg.n_stems < 2) return fail(-1, "srtSeparateCli: the engine needs sub-networks 0 (drum) and 1 (vocal)");
-    if (e->cfg.ratio_mask) return fail(-1, "srtSeparateCli: ratio_mask does not apply to the CLI flows (the sub-networks see different inputs)");
-    if (n < SRT_FFT) return fail(-1, "srtSeparateCli: need at least 4096 samples");
+    TimerScope ts(e, "residual");
+    const int rc = stems == 2 ? srt_launch_time_residual(d_L, d_R, n, d_out, len, d_out + 2 * len, e->stream)
+                              : srt_launch_time_residual(d_out + 4 * len, d_out + 5 * len, len, d_out + 2 * len, len, d_out + 4 * len, e->stream);
+    return rc ? fail(-2, "residual launch failed") : 0;
+}
+
+static int cli_issue(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, int stems, float* d_out, bool residual_now)
+{
     const int T = e->cfg.T;
-    const size_t rows = srtStftRows(n), frames = srtStftFrames(n), ntiles = (rows + T - 1) / T, len = srtIstftLength(rows);
-    if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparateCli: signal longer than max_tiles * T frames");
+    const size_t ntiles = (rows + T - 1) / T, len = srtIstftLength(rows);
     const size_t HW2 = 2 * (size_t)T * e->cfg.F;
     float* mask0 = e->masks;                                  // stem stride of this batch = ntiles instances
     float* mask1 = e->masks + ntiles * HW2;
@@ -627,9 +685,7 @@ int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, 
     if (stems == 2) {
         if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 1, 1))) return rc;
         if ((rc = istft_one(e, e->spec, rows, mask1, e->cfg.oob_weight[1], d_out, "istft"))) return rc;
-        TimerScope ts(e, "residual");
-        if (srt_launch_time_residual(d_L, d_R, n, d_out, len, d_out + 2 * len, e->stream)) return fail(-2, "residual launch failed");
-        return 0;
+        return residual_now ? cli_time_residual(e, d_L, d_R, n, stems, d_out, len) : 0;
     }
     if (!e->spec2) HIPCHK(hipMalloc((void**)&e->spec2, (size_t)2 * e->rows_cap * SRT_SPEC_LD * sizeof(float2)));
     if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 0, 1))) return rc;
@@ -644,9 +700,28 @@ int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, 
     if ((rc = istft_one(e, e->spec2, rows, nullptr, 1.0f, d_out + 4 * len, "istft"))) return rc;                      // accompaniment + vocal
     if ((rc = forward_range(e, e->mag, (int)ntiles, e->masks, 1, 1))) return rc;
     if ((rc = istft_one(e, e->spec2, rows, mask1, e->cfg.oob_weight[1], d_out + 2 * len, "istft"))) return rc;       // Vocal
-    TimerScope ts(e, "residual");
-    if (srt_launch_time_residual(d_out + 4 * len, d_out + 5 * len, len, d_out + 2 * len, len, d_out + 4 * len, e->stream)) return fail(-2, "residual launch failed");
+    return residual_now ? cli_time_residual(e, d_L, d_R, n, stems, d_out, len) : 0;
+}
+
+static int cli_check(srt_engine* e, int stems)
+{
+    if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
+    if (e->cfg.n_stems < 2) return fail(-1, "srtSeparateCli: the engine needs sub-networks 0 (drum) and 1 (vocal)");
+    if (e->cfg.ratio_mask) return fail(-1, "srtSeparateCli: ratio_mask does not apply to the CLI flows (the sub-networks see different inputs)");
     return 0;
+}
+
+int srtSeparateCli(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out)
+{
+    if (!e || !d_L || !d_R || !d_out) return fail(-1, "srtSeparateCli: null argument");
+    DeviceScope ds(e->device);
+    int rc = cli_check(e, stems);
+    if (rc) return rc;
+    if (n < SRT_FFT) return fail(-1, "srtSeparateCli: need at least 4096 samples");
+    const int T = e->cfg.T;
+    const size_t rows = srtStftRows(n), frames = srtStftFrames(n), ntiles = (rows + T - 1) / T;
+    if (ntiles > (size_t)e->cfg.max_tiles) return fail(-1, "srtSeparateCli: signal longer than max_tiles * T frames (srtSeparateCliHost walks longer files chunk by chunk)");
+    return cli_issue(e, d_L, d_R, n, frames, rows, stems, d_out, true);
 }
 
 // Grow-only device staging shared by the host-buffer entry points (kept in the engine, freed by srtDestroy).
@@ -687,15 +762,24 @@ static int ensure_staging(srt_engine* e, size_t in_floats, size_t out_floats, si
     return 0;
 }
 
-// Host-buffer convenience over srtSeparateCli for plain-C callers (the CLI harness): H2D, chain, D2H, synchronous.
-// The device copies of the input and the outputs live in the engine's staging buffers (grown on demand, reused by later calls).
+static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems);
+
+// Host-buffer form of srtSeparateCli for plain-C callers (the CLI harness): synchronous.  A file that fits the engine's capacity
+// (max_tiles tiles) is one resident batch: H2D, chain, D2H.  A longer one - any length, as the reference's tile loop over a
+// host-resident spectrogram handles (main.c:455-495) - goes through the chunked pipeline of srtSeparateHostStream: max_tiles tiles
+// at a time, copies overlapped with compute, the residual chain evaluated per chunk (it is row-local) and the time-domain
+// subtraction applied after the 3072-sample chunk overlaps have been added on the device.
 int srtSeparateCliHost(srt_engine* e, const float* h_L, const float* h_R, size_t n, int stems, float* h_out)
 {
     if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateCliHost: null argument");
-    if (stems != 2 && stems != 3) return fail(-1, "srtSeparateCli: stems must be 2 or 3");
     DeviceScope ds(e->device);
-    const size_t len = srtIstftLength(srtStftRows(n));
-    int rc = ensure_staging(e, 2 * n, (size_t)stems * 2 * len, 0, 1);
+    int rc = cli_check(e, stems);
+    if (rc) return rc;
+    if (n < SRT_FFT) return fail(-1, "srtSeparateCli: need at least 4096 samples");
+    const size_t rows = srtStftRows(n), len = srtIstftLength(rows);
+    if ((rows + e->cfg.T - 1) / e->cfg.T > (size_t)e->cfg.max_tiles)
+        return host_stream(e, h_L, h_R, n, srtStftFrames(n), rows, h_out, 0, stems);
+    rc = ensure_staging(e, 2 * n, (size_t)stems * 2 * len, 0, 1);
     if (rc) return rc;
     float *d_in = e->hs.d_in[0], *d_out = e->hs.d_out[0];
     hipError_t er = hipMemcpyAsync(d_in, h_L, n * sizeof(float), hipMemcpyHostToDevice, e->stream);
@@ -707,6 +791,7 @@ int srtSeparateCliHost(srt_engine* e, const float* h_L, const float* h_R, size_t
         if (er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
     }
     hipStreamSynchronize(e->stream);
+    free_staging(e);                                           // whole-file device copies of a one-shot call: not kept until srtDestroy
     return rc;
 }
 
@@ -721,12 +806,13 @@ int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, flo
 // and the 3072-sample overlap between consecutive chunks is added on the device (srt_carry_kernel), so every output
 // sample crosses PCIe exactly once.  Geometry as srtSeparateEx (a tile range of a longer stream: rows = whole tiles,
 // frames = rows; the whole stream: rows = srtStftRows(n), frames = srtStftFrames(n)).
-int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags)
+// cli_stems = 0: the n_stems sub-networks on the same input (srtSeparateEx per chunk); 2 / 3: the CLI's flows (cli_issue per chunk)
+static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems)
 {
     if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateHostStream: null argument");
     if (rows < 1 || frames > rows) return fail(-1, "srtSeparateHostStream: need 1 <= frames <= rows");
     DeviceScope ds(e->device);
-    const int S = e->cfg.n_stems, T = e->cfg.T, NP = S * 2;
+    const int S = cli_stems ? cli_stems : e->cfg.n_stems, T = e->cfg.T, NP = S * 2;
     const size_t chunk_rows = (size_t)e->cfg.max_tiles * T, tail = SRT_FFT - SRT_HOP;
     const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows, total_len = srtIstftLength(rows);
     const size_t in_cap = chunk_rows * SRT_HOP + tail, out_cap = srtIstftLength(chunk_rows);
@@ -763,9 +849,12 @@ int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, s
         STEP(hipStreamWaitEvent(e->stream, h.ev_in[b], 0));
         if (c >= 2) STEP(hipStreamWaitEvent(e->stream, h.ev_out[b], 0));
         if (er != hipSuccess) break;
-        rc = srtSeparateEx(e, h.d_in[b], h.d_in[b] + in_cap, ns, cfr, crow, h.d_out[b]);
+        rc = cli_stems ? cli_issue(e, h.d_in[b], h.d_in[b] + in_cap, ns, cfr, crow, cli_stems, h.d_out[b], false)
+                       : srtSeparateEx(e, h.d_in[b], h.d_in[b] + in_cap, ns, cfr, crow, h.d_out[b]);
         if (rc) break;
         if (srt_launch_carry(h.d_out[b], clen, NP, crow * SRT_HOP, h.d_carry, c == 0, c + 1 == nchunks, e->stream)) { rc = fail(-2, "carry launch failed"); break; }
+        // CLI flows: the time-domain subtraction comes after the seam has been added (the planes now hold the stitched signals)
+        if (cli_stems && (rc = cli_time_residual(e, h.d_in[b], h.d_in[b] + in_cap, ns, cli_stems, h.d_out[b], clen))) break;
         STEP(hipEventRecord(h.ev_cmp[b], e->stream));
         // download: every plane's [0, crow*1024) (+ the final 3072 on the last chunk) lands at its place in h_out
         STEP(hipStreamWaitEvent(h.s_out, h.ev_cmp[b], 0));
@@ -782,6 +871,11 @@ int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, s
     if (pinR) hipHostUnregister((void*)h_R);
     if (pinO) hipHostUnregister((void*)h_out);
     return rc;
+}
+
+int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags)
+{
+    return host_stream(e, h_L, h_R, n, frames, rows, h_out, flags, 0);
 }
 
 int srtSeparateHostStream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out)
@@ -847,6 +941,43 @@ int srtGetTiming(srt_engine* e, char* names, size_t names_bytes, float* ms, int 
         float v = 0; hipEventElapsedTime(&v, t.a, t.b);
         ms[n++] = v;
         if (names && used + t.name.size() + 2 < names_bytes) { memcpy(names + used, t.name.c_str(), t.name.size()); used += t.name.size(); names[used++] = ','; names[used] = 0; }
+    }
+    return n;
+}
+
+// The kernel that ran each timed launch (same order and count as srtGetTiming), ';'-separated, as rocprofv3 prints kernel names:
+// the demangled symbol without its return type and argument list, e.g. "srt_dec_wino<4, 16, 1, 0>".  For a split-K layer this is
+// the layer kernel (the reduction that follows it is not named).  If the runtime cannot resolve a symbol the launch expression's
+// source text is reported instead.
+int srtGetTimingKernels(srt_engine* e, char* kernels, size_t kernels_bytes)
+{
+    if (!e || !kernels || !kernels_bytes) return fail(-1, "srtGetTimingKernels: bad argument");
+    DeviceScope ds(e->device);
+    kernels[0] = 0;
+    size_t used = 0; int n = 0;
+    for (auto& t : e->tlog) {
+        std::string nm;
+        const char* sym = t.kfn ? hipKernelNameRefByPtr(t.kfn, e->stream) : nullptr;
+        (void)hipGetLastError();
+        if (sym && sym[0]) {
+            int st = 0;
+            char* dm = abi::__cxa_demangle(sym, nullptr, nullptr, &st);
+            nm = (st == 0 && dm) ? dm : sym;
+            free(dm);
+            if (!nm.compare(0, 5, "void ")) nm.erase(0, 5);
+            // cut the argument list: the '(' that closes the name is the first one outside template brackets
+            int depth = 0;
+            for (size_t i = 0; i < nm.size(); ++i) {
+                if (nm[i] == '<') ++depth; else if (nm[i] == '>') --depth;
+                else if (nm[i] == '(' && depth == 0) { nm.erase(i); break; }
+            }
+        } else if (t.ktext) {
+            nm = t.ktext;
+            if (nm.size() >= 2 && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
+        } else nm = "?";
+        if (used + nm.size() + 2 >= kernels_bytes) break;
+        memcpy(kernels + used, nm.c_str(), nm.size()); used += nm.size(); kernels[used++] = ';'; kernels[used] = 0;
+        ++n;
     }
     return n;
 }

@@ -19,6 +19,14 @@ int srt_set_error(int code, const char* fmt, const char* detail);
 
 enum { SRT_ACT_LEAKY = 0, SRT_ACT_RELU = 1, SRT_ACT_ELU = 2 };
 
+// Every kernel launch of the library goes through SRT_LAUNCH: besides launching, it notes WHICH kernel (host stub pointer + the
+// launch expression's text) the calling thread launched first since srt_kernel_note_reset().  The engine's per-launch timers keep
+// that with each entry, so srtGetTimingKernels() reports the kernel that actually ran a layer (the dispatch depends on batch
+// size and geometry), not a table kept by hand.
+void srt_kernel_note(const void* fn, const char* text);
+void srt_kernel_note_reset();
+#define SRT_LAUNCH(kernel, ...) do { srt_kernel_note((const void*)(kernel), #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+
 // One convolution layer evaluated for nstems x ntiles independent instances.
 // instance pointer = base + stem * *_stem + tile * *_tile   (strides in floats)
 struct SrtConvParams {

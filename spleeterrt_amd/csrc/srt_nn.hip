@@ -113,7 +113,7 @@ __global__ void srt_bn_act_kernel(const float* __restrict__ raw, int raw16, floa
 }
 int srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, raw16, out, scale, shift, C, hw, kind, variant);
+    SRT_LAUNCH(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, raw16, out, scale, shift, C, hw, kind, variant);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 __global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t n)
@@ -122,7 +122,7 @@ __global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float
 }
 int srt_launch_half_to_float(const void* src, float* dst, size_t n, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_half_to_float_kernel, dim3(1024), dim3(256), 0, s, (const _Float16*)src, dst, n);
+    SRT_LAUNCH(srt_half_to_float_kernel, dim3(1024), dim3(256), 0, s, (const _Float16*)src, dst, n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -239,12 +239,12 @@ __global__ void srt_pack_kernel(const float* __restrict__ w, float* __restrict__
 }
 int srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 0);
+    SRT_LAUNCH(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 0);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 1);
+    SRT_LAUNCH(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -260,7 +260,7 @@ __global__ void srt_fp16_expand_kernel(const uint16_t* __restrict__ in, float* _
 }
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_fp16_expand_kernel, dim3(2048), dim3(256), 0, s, d_in, d_out, n);
+    SRT_LAUNCH(srt_fp16_expand_kernel, dim3(2048), dim3(256), 0, s, d_in, d_out, n);
 }
 
 // ------------------------------------------------------------------------------------------- MFMA encoder
@@ -696,7 +696,7 @@ static int launch_enc_cfg(const SrtConvParams& p, hipStream_t s)
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     const int Ho = p.H / 2, Wo = p.W / 2;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
-    hipLaunchKernelGGL((srt_enc_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
+    SRT_LAUNCH((srt_enc_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
@@ -704,7 +704,7 @@ static int launch_dec_cfg(const SrtConvParams& p, hipStream_t s)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
-    hipLaunchKernelGGL((srt_dec_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
+    SRT_LAUNCH((srt_dec_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -712,7 +712,7 @@ static int launch_naive(void (*k)(const SrtConvParams), const SrtConvParams& p, 
 {
     size_t bx = (total + 255) / 256;
     if (bx > 65535) bx = 65535;
-    hipLaunchKernelGGL(k, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
+    SRT_LAUNCH(k, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -735,7 +735,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
     if ((p.in16 || p.out16) && !(impl == 0 && p.Cout == 1 && p.Cin == 32 && !p.out16)) return -1;   // only up6 reads fp16 tensors here
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
-#define UP6_LAUNCH(TH, TW) hipLaunchKernelGGL((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.nstems * p.ntiles), dim3(256), 0, s, p)
+#define UP6_LAUNCH(TH, TW) SRT_LAUNCH((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.nstems * p.ntiles), dim3(256), 0, s, p)
         int v = 0;
 #ifdef SRT_TUNING
         const char* tv = getenv("SRT_TUNE_UP6");
@@ -745,7 +745,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 3) UP6_LAUNCH(4, 64);
         else if (v == 4) UP6_LAUNCH(4, 128);
 #endif
-        if (v == 0 && p.in16) hipLaunchKernelGGL((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+        if (v == 0 && p.in16) SRT_LAUNCH((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
         else if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -765,12 +765,12 @@ int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
 #endif
         if (bx4 > 65535) bx4 = 65535;
         const unsigned grid = (unsigned)bx4 * p.nstems * p.ntiles;
-        if (p.variant == 0) hipLaunchKernelGGL(srt_head_kernel4<true>, dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(srt_head_kernel4<false>, dim3(grid), dim3(256), 0, s, p);
+        if (p.variant == 0) SRT_LAUNCH(srt_head_kernel4<true>, dim3(grid), dim3(256), 0, s, p);
+        else SRT_LAUNCH(srt_head_kernel4<false>, dim3(grid), dim3(256), 0, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     size_t total = (size_t)p.H * p.W, bx = (total + 255) / 256;
     if (bx > 65535) bx = 65535;
-    hipLaunchKernelGGL(srt_head_kernel, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
+    SRT_LAUNCH(srt_head_kernel, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -34,7 +34,7 @@ __global__ void srt_pack16_kernel(const float* __restrict__ w, _Float16* __restr
 }
 int srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s)
 {
-    hipLaunchKernelGGL(srt_pack16_kernel, dim3(1024), dim3(256), 0, s, w, (_Float16*)wp16, Cin, Cout, CP, dec);
+    SRT_LAUNCH(srt_pack16_kernel, dim3(1024), dim3(256), 0, s, w, (_Float16*)wp16, Cin, Cout, CP, dec);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -451,9 +451,9 @@ static int launch_dec16(const SrtConvParams& p, hipStream_t s)
 {
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
-    if (p.nsplit == 2) hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
-    else if (p.in16) hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((srt_dec_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
+    if (p.nsplit == 2) SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else if (p.in16) SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
+    else SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int SW, int NSX, int NSY, int NI>
@@ -462,9 +462,9 @@ static int launch_enc16(const SrtConvParams& p, hipStream_t s)
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     const int Ho = p.H / 2, Wo = p.W / 2;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.Cout + 31) / 32) * p.nstems * ((p.ntiles + NI - 1) / NI));
-    if (p.nsplit == 2) hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
-    else if (p.in16) hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((srt_enc_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
+    if (p.nsplit == 2) SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
+    else if (p.in16) SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
+    else SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

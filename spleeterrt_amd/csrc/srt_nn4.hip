@@ -87,7 +87,7 @@ __global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restr
 int srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s)
 {
     if (Cin % 4 || Cout % 16) return -1;
-    hipLaunchKernelGGL(srt_pack_wino_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
+    SRT_LAUNCH(srt_pack_wino_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -450,18 +450,18 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const dim3 grid((unsigned)(wgs / tpw));
 #ifdef SRT_TUNING
         switch (wino_tune("winoabl=")) {
-        case 1: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 2: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 3: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 4: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 5: hipLaunchKernelGGL((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 1: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 2: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 3: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         }
 #endif
-        hipLaunchKernelGGL((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
     } else if (p.H >= 4 && p.W >= 16) {
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 3) / 4), wgs = units * MB * p.nstems;
         const int tpw = wino_tpw(wgs, units);
-        hipLaunchKernelGGL((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
     } else return 1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -147,6 +147,11 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         INITTRY(hipMemset(s->d_spec, 0, specF * sizeof(float)));              // zero spectrum for the first 2T hops (:423-438)
         INITTRY(hipMemset(s->d_mag, 0, 2 * s->hw * sizeof(float)));
         INITTRY(hipMemset(s->d_overlap, 0, 8 * 1024 * sizeof(float)));
+        // Pre-warm on THIS thread: the split-K workspace allocation and the capture + instantiation of one hipGraph per mask buffer
+        // would otherwise happen inside the host's audio callback at hops T and 2T (an allocation and a graph build there risk a dropout).
+        INITTRY(hipMemset(s->d_tmp, 0, 2 * s->hw * sizeof(float)));
+        for (int b = 0; b < 2; ++b)
+            if (srtPrepareForward(s->eng, s->d_tmp, 1, s->d_masks + (size_t)b * 4 * 2 * s->hw)) { stream_fail("Spleeter4StemsInit(prepare)", nullptr); return; }
         std::vector<float> ones(2 * 4 * 2 * s->hw, 1.0f), an, sy, tw(2 * FFTSIZE);                 // masks start at 1.0 (:456-467)
         INITTRY(hipMemcpy(s->d_masks, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
         asymmetric_window(an, sy);

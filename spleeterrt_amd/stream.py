@@ -99,6 +99,24 @@ def stitch(parts, n, nstems):
     return out
 
 
+def init_distributed(device=None):
+    """One process per GPU.  Under a torch.distributed launcher (RANK / WORLD_SIZE / MASTER_ADDR in the environment) join the
+    process group - `nccl` (= RCCL on ROCm) when `device` is a GPU, gloo otherwise - at ANY world size, 1 included: a world of one
+    still loads RCCL and runs the weight broadcast, so the N > 1 code path is the one that always runs.  Returns (rank, world, on)."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+        if device is not None and str(device).startswith("cuda"):
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    return rank, world, dist.is_initialized()
+
+
 def broadcast_weights(coeffs, device=None, src=0):
     """The one collective of the path: rank `src` holds the blobs (list of float32 arrays/tensors, one per stem),
     every rank gets them (RCCL over xGMI when the process group is `nccl`, gloo on CPU)."""
@@ -106,7 +124,7 @@ def broadcast_weights(coeffs, device=None, src=0):
     import torch.distributed as dist
     n = 9822725
     k = [len(coeffs) if coeffs is not None else 0]
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast_object_list(k, src)
     out = []
     for s in range(k[0]):
@@ -114,7 +132,7 @@ def broadcast_weights(coeffs, device=None, src=0):
             t = torch.as_tensor(coeffs[s], dtype=torch.float32).reshape(-1).to(device or "cpu")
         else:
             t = torch.empty(n, dtype=torch.float32, device=device or "cpu")
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():
             dist.broadcast(t, src)
         out.append(t)
     return out

@@ -98,6 +98,16 @@ def test_cli_argument_and_input_validation(tmp_path):
     assert r.returncode != 0 and b"only 44.1 kHz" in r.stderr
     r = subprocess.run([cli, "1", "64", "512", "2", str(wav)], capture_output=True, env=env)
     assert r.returncode != 0 and b"no weights" in r.stderr
+    # beyond 4 GiB: RF64 containers and streamed data chunks of unknown length fail with a message, not with a wrapped 32-bit size
+    rf = tmp_path / "big.wav"
+    rf.write_bytes(b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVEds64" + bytes(64))
+    r = subprocess.run([cli, "1", "64", "512", "2", str(rf), str(w)], capture_output=True, env=env)
+    assert r.returncode != 0 and b"RF64" in r.stderr
+    st = tmp_path / "stream.wav"
+    st.write_bytes(b"RIFF" + struct.pack("<I", 0xFFFFFFFF) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16)
+                   + b"data" + struct.pack("<I", 0xFFFFFFFF) + pcm)
+    r = subprocess.run([cli, "1", "64", "512", "2", str(st), str(w)], capture_output=True, env=env)
+    assert r.returncode != 0 and b"unknown length" in r.stderr
 
 
 def test_tuning_build_still_compiles():
@@ -115,21 +125,27 @@ def test_tuning_build_still_compiles():
         assert r.returncode == 0, r.stderr.decode()[-2000:]
 
 
-def test_bench_kernel_symbols_exist_in_the_library(lib):
-    """bench.py attributes per-layer times and the rocprofv3 PMC summaries to kernel SYMBOLS (LAYER_SYMBOL).  A template signature that
-    changed without the table (it happened once) silently turns `roofline.traffic` into null: every symbol named there must be a
-    kernel of the built library."""
+def test_bench_takes_kernel_names_from_the_engine(lib):
+    """bench.py no longer keeps a layer -> kernel-symbol table: the engine reports the symbol of every timed launch
+    (srtGetTimingKernels, GPU-tested in tests/test_gpu_parity.py).  What can still go stale is the committed PMC summary bench.py
+    reads `roofline.traffic` / `mfma_busy_frac` from: every MFMA layer kernel named in the NEWEST summary must be a kernel of the built
+    library (a template signature that changed without a refreshed profile would silently turn those fields into null)."""
+    import json
     import shutil
     import sys
     if not shutil.which("nm"):
         pytest.skip("nm not available")
     sys.path.insert(0, ROOT)
     import bench
+    assert not hasattr(bench, "LAYER_SYMBOL")
     out = subprocess.run(["nm", "-C", lib[1]], capture_output=True, text=True).stdout
     have = set()
     for ln in out.splitlines():
         m = re.search(r"(?:void )?(?:__device_stub__)?(srt_\w+(?:<[^(]*>)?)\(", ln)
         if m:
             have.add(m.group(1))
-    missing = {k: v for k, v in bench.LAYER_SYMBOL.items() if v not in have}
-    assert not missing, "bench.LAYER_SYMBOL names kernels the library does not contain: %r" % (missing,)
+    newest = next(p for p in bench.PMC_SUMMARIES if os.path.exists(p))
+    named = [k for k in json.load(open(newest)) if re.match(r"srt_(enc|dec|up6|head)\w*<", k)]
+    assert named, newest
+    missing = [k for k in named if k not in have]
+    assert not missing, "%s names kernels the library does not contain (re-run scripts/profile_gpu.sh): %r" % (newest, missing)

@@ -142,3 +142,27 @@ def test_baseline_config0_ten_second_clip(workdir, oracle, stems):
         assert a.shape == r.shape == (n, 2)
         assert _rel_rms(a, r) <= 1e-4, "%s: rel rms %g" % (nm, _rel_rms(a, r))
         assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max()
+
+
+def test_cli_program_walks_long_files_in_chunks(workdir, oracle):
+    """The CLI binary with a small engine capacity (SPLEETERRT_MAX_TILES=3: the 10 s clip is 8 tiles of 64 frames -> 3 chunks, the last
+    ragged) writes the same three files as with the default capacity (one resident batch): any file length works, as with the
+    reference's tile-at-a-time loop (main.c:455-495).  SPLEETERRT_BATCH_INVARIANT=1 pins the kernel choice, so only the overlap-add
+    association at the two chunk seams differs."""
+    cli = os.path.join(HOST, "spleeterrt_cli")
+    subprocess.check_call(["make", "-s", "-C", HOST, "spleeterrt_cli"])
+    n = 441000
+    L, R = oracle.synth_audio(n, 4321, True)
+    _write_wav16(workdir / "long.wav", L * 4.0, R * 4.0)
+    outs = {}
+    for tag, extra in (("resident", {}), ("chunked", {"SPLEETERRT_MAX_TILES": "3"})):
+        d = workdir / tag
+        d.mkdir(exist_ok=True)
+        env = dict(os.environ, SPLEETERRT_VARIANT="exe", SPLEETERRT_BATCH_INVARIANT="1", **extra)
+        txt = subprocess.check_output([cli, "1", "64", "512", "3", str(workdir / "long.wav"), str(workdir / "weights.f16")], cwd=d, env=env).decode()
+        assert ("in chunks of 3" in txt) == (tag == "chunked"), txt
+        outs[tag] = {nm: _read_wav_f32(d / ("long.wav_%s.wav" % nm)) for nm in ("Drum", "Vocal", "Accompaniment")}
+    for nm in outs["resident"]:
+        a, r = outs["chunked"][nm], outs["resident"][nm]
+        assert a.shape == r.shape == (n, 2)
+        assert np.abs(a - r).max() <= 2e-6 * np.abs(r).max(), nm

@@ -29,6 +29,38 @@ def _rel_rms(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
 
 
+TAP_RMS_TOL = 2e-5          # every intermediate tensor, relative to its own RMS
+TAP_MAX_TOL = 1e-4          # ... and its worst single element relative to the tensor's peak: a handful of wrong border pixels in a
+                            # multi-million-element tensor passes an RMS bound, it cannot pass this one
+
+
+def _check_taps(eng, oracle, coeff, x_tile, mode, s, t, masks=None, tag=""):
+    """every tensor of instance (stem s, tile t) against the oracle: rel-RMS AND max-abs / peak; returns the worst of each"""
+    y, taps = oracle.forward(coeff, x_tile, mode, oracle.VARIANT_VST, want_taps=True)
+    worst_r = worst_m = 0.0
+    for name, ref in taps.items():
+        got = eng.tensor(name, s, t)
+        err = _rel_rms(got, ref)
+        mx = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+        where = np.unravel_index(int(np.abs(got - ref).argmax()), ref.shape)
+        assert err < TAP_RMS_TOL, "%s %s stem %d tile %d: rel rms %g (max abs / peak %g at %r)" % (tag, name, s, t, err, mx, where)
+        assert mx < TAP_MAX_TOL, "%s %s stem %d tile %d: max abs / peak %g at %r of %r (rel rms %g)" % (tag, name, s, t, mx, where, ref.shape, err)
+        worst_r, worst_m = max(worst_r, err), max(worst_m, mx)
+    if masks is not None:
+        d = float(np.abs(masks[s, t] - y).max())
+        assert d <= MASK_TOL_EXACT, "%s mask stem %d tile %d: max abs %g" % (tag, s, t, d)
+    return worst_r, worst_m
+
+
+def _layer_kernels(eng, xd):
+    """layer name -> kernel symbol the engine launched for it in one forward (srtGetTimingKernels)"""
+    eng.set_timing(True)
+    eng.forward(xd)
+    ks = dict(eng.get_timing_kernels())
+    eng.set_timing(False)
+    return ks
+
+
 @pytest.mark.parametrize("impl", ["naive", "mfma"])
 @pytest.mark.parametrize("T,F", [(64, 512), (128, 1024)])
 def test_forward_layers(oracle, coeffs, impl, T, F):
@@ -42,20 +74,12 @@ def test_forward_layers(oracle, coeffs, impl, T, F):
         eng.set_coeff(s, coeffs(s))
     x = _mag_input(oracle, ntiles, T, F)
     masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
-    worst = 0.0
+    worst = (0.0, 0.0)
     for s in range(2):
         for t in range(ntiles):
-            y, taps = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST, want_taps=True)
-            for name, ref in taps.items():
-                got = eng.tensor(name, s, t)
-                err = _rel_rms(got, ref)
-                assert err < 2e-5, "%s stem %d tile %d impl %s: rel rms %g, max abs %g (ref rms %g)" % (
-                    name, s, t, impl, err, np.abs(got - ref).max(), np.sqrt(np.mean(ref ** 2)))
-            d = np.abs(masks[s, t] - y).max()
-            worst = max(worst, d)
-            assert d <= MASK_TOL_EXACT, "mask stem %d tile %d impl %s: max abs %g" % (s, t, impl, d)
+            worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, impl))
     eng.close()
-    print("forward %s %dx%d worst mask err %.3g" % (impl, T, F, worst))
+    print("forward %s %dx%d worst tap rel-rms %.3g, max-abs/peak %.3g" % (impl, T, F, worst[0], worst[1]))
 
 
 @pytest.mark.parametrize("T,F,check", [(64, 512, (0, 4, 8)), (128, 1024, (8,))])
@@ -72,17 +96,60 @@ def test_winograd_decoder_layers(oracle, coeffs, T, F, check):
     for s in range(2):
         eng.set_coeff(s, coeffs(s))
     x = _mag_input(oracle, ntiles, T, F, seed=99)
-    masks = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
     assert np.isfinite(masks).all()
     for s in range(2):
         for t in check:
-            y, taps = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST, want_taps=True)
-            for name, ref in taps.items():
-                got = eng.tensor(name, s, t)
-                err = _rel_rms(got, ref)
-                assert err < 2e-5, "%s stem %d tile %d: rel rms %g, max abs %g" % (name, s, t, err, np.abs(got - ref).max())
-            assert np.abs(masks[s, t] - y).max() <= MASK_TOL_EXACT
+            _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks)
+    ks = _layer_kernels(eng, xd)
+    for name in ("up3", "up4", "up5") + (("up2",) if T >= 128 else ()):
+        assert ks[name].startswith("srt_dec_wino<"), (name, ks[name])
+    assert not ks["up1"].startswith("srt_dec_wino<")
     eng.close()
+
+
+def _wino_expected(T, F, lvl):
+    """does up<lvl> (lvl = 2..5) of a T x F engine fit the Winograd kernels' geometry (csrc/srt_nn4.hip: H even, W % 4 == 0, H >= 4, W >= 16)"""
+    H, W = T >> (7 - lvl), F >> (7 - lvl)
+    return H % 2 == 0 and W % 4 == 0 and H >= 4 and W >= 16
+
+
+@pytest.mark.parametrize("T,F,ntiles,stems,check_stems", [
+    (256, 1536, 5, 4, (0, 3)),      # the plugin's geometry (PluginProcessor.cpp:124) as a 20-instance batch: up2 is 8 x 48 (half-empty x tile)
+    (192, 320, 9, 2, (0, 1)),       # up2 W = 10 (not a multiple of 4: direct kernel), up3 12 x 20 on the 4-instance tile with a partly empty group
+    (64, 576, 9, 2, (0, 1)),        # up2 2 x 18 -> direct, up3 4 x 36 (smallest height), up4 8 x 72, up5 16 x 144: partial x tiles everywhere
+    (320, 1984, 5, 4, (1, 2)),      # up2 10 x 62 -> direct; up3 20 x 124, up4 40 x 248, up5 80 x 496: partial tiles in both directions
+    (128, 1024, 17, 1, (0,)),       # one stem, odd tile count just over the 16-instance switch: ragged instance groups, tpw > 1
+])
+def test_winograd_decoder_odd_geometries(oracle, coeffs, T, F, ntiles, stems, check_stems):
+    """the Winograd decoder kernels (38 % of the headline step) on batches above 16 instances at NON-power-of-two
+    geometries: partial spatial tiles (W % 32 != 0, H % 8 != 0: the out-of-range zero fill and the blk_ok store guard), the
+    4-instance tile with a partly empty instance group, several units per workgroup, and the clean fall-back to the direct kernels
+    where W % 4 != 0.  Every tensor of the first, the last and one interior tile: rel-RMS and max-abs / peak; the kernel that ran
+    each decoder layer is read back from the engine and must be the Winograd one exactly where the geometry fits."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))          # mixed activation pairs inside one launch
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, impl=srt.IMPL_MFMA)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=500 + T + F)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    assert np.isfinite(masks).all()
+    worst = (0.0, 0.0)
+    for s in check_stems:
+        for t in sorted({0, ntiles // 2, ntiles - 1}):
+            worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, "T=%d F=%d" % (T, F)))
+    ks = _layer_kernels(eng, xd)
+    for lvl in (2, 3, 4, 5):
+        name = "up%d" % lvl
+        assert ks[name].startswith("srt_dec_wino<") == _wino_expected(T, F, lvl), (name, ks[name], T >> (7 - lvl), F >> (7 - lvl))
+    assert not ks["up1"].startswith("srt_dec_wino<") and not ks["up6"].startswith("srt_dec_wino<")
+    eng.close()
+    print("wino odd geometry %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g; %s" % (
+        T, F, ntiles, stems, worst[0], worst[1], {k: v for k, v in ks.items() if k.startswith("up")}))
 
 
 def test_forward_lut_variant(oracle, coeffs):
@@ -321,7 +388,7 @@ def test_rejects_bad_arguments():
 
 
 @pytest.mark.parametrize("prec,mask_tol", [("f16", 2e-2), ("f16x2", MASK_TOL_EXACT)])
-@pytest.mark.parametrize("T,F", [(64, 512), (128, 1024)])
+@pytest.mark.parametrize("T,F", [(64, 512), (128, 1024), (64, 576)])    # F = 576: not a multiple of 256 -> fp32 tensors, BN + activation applied by the consuming fp16 encoder
 def test_fp16_mfma_variants(oracle, coeffs, prec, mask_tol, T, F):
     """BASELINE configs[4]: fp16 MFMA conv (fp32 accumulate, fp32 STFT/iSTFT) against the CPU fp32 oracle.
     f16   : activations rounded to fp16         -> mask max-abs <= 2e-2
@@ -406,6 +473,42 @@ def test_cli_flow_device_resident(oracle, coeffs, stems):
     eng.close()
 
 
+@pytest.mark.parametrize("stems,minutes,max_tiles", [(3, 30.0, 16), (2, 2.0, 3), (3, 0.5, 1)])
+def test_cli_flow_any_length_chunked_equals_resident(oracle, coeffs, stems, minutes, max_tiles):
+    """VERDICT r2 missing #2 / next #7: the reference CLI walks its tiles one at a time over a host-resident spectrogram, so any file
+    length works (main.c:455-495).  srtSeparateCliHost on an engine of max_tiles tiles walks a longer file chunk by chunk (uploads,
+    residual chain and downloads overlapped; chunk seams added on the device BEFORE the time-domain subtraction) and must equal the
+    one-resident-batch flow (itself oracle-tested in test_cli_flow_device_resident) to 2e-6 of the peak, for both output counts,
+    chunk sizes that do and do not divide the file, down to one tile per chunk.  The first case is a 30-minute file at max_tiles = 16."""
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    n = int(minutes * 60 * 44100) // 4096 * 4096 + 8192 + 333     # ragged tail tile
+    rng = np.random.default_rng(1234)
+    L = (rng.random(n, dtype=np.float32) - 0.5) * 0.2
+    R = (rng.random(n, dtype=np.float32) - 0.5) * 0.2
+    rows = (n + 1023) // 1024
+    ntiles = (rows + T - 1) // T
+    assert ntiles > max_tiles
+    kw = dict(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, batch_invariant=True)      # same kernels in both engines: what differs is the seams
+    big = _engine(max_tiles=ntiles, **kw)
+    for s in range(2):
+        big.set_coeff(s, coeffs(s))
+    ref = big.separate_cli_host(L, R, stems)
+    big.close()
+    eng = _engine(max_tiles=max_tiles, **kw)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    got = eng.separate_cli_host(L, R, stems)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    peak = np.abs(ref).max()
+    for k in range(stems):
+        assert np.abs(got[k] - ref[k]).max() <= 2e-6 * peak, "output %d: %g of the peak" % (k, np.abs(got[k] - ref[k]).max() / peak)
+    if minutes < 1:
+        again = eng.separate_cli_host(L, R, stems)          # reusable, deterministic
+        assert np.array_equal(got, again)
+    eng.close()
+
+
 def test_forward_stem_range_equals_full(oracle, coeffs):
     """srtForwardStems on [1,2) then [0,1) fills the same mask tensor as one srtForward over both sub-networks."""
     import torch
@@ -429,6 +532,47 @@ def test_forward_stem_range_equals_full(oracle, coeffs):
     with pytest.raises(srt.EngineError):
         eng.forward_stems(x, part, 1, 2)
     eng.close()
+
+
+def test_batch_invariant_switch(oracle, coeffs):
+    """srt_config.batch_invariant: kernel choice by layer geometry only, no split-K - a tile's masks are bit-identical
+    whatever the batch size, its slot, the stem range of the launch or the chunking, as on the reference's CPU path; and they still
+    match the oracle.  The default mode (fastest kernel per launch size) is held to 1e-4 by the tests above."""
+    import torch
+    import spleeterrt_amd as srt
+    from spleeterrt_amd import stream
+    T, F, NT = 64, 512, 20
+    x = _mag_input(oracle, NT, T, F, seed=2718)
+    xd = torch.from_numpy(x).cuda()
+    eng = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=NT, batch_invariant=True)
+    for s in range(2):
+        eng.set_coeff(s, coeffs(s))
+    full = eng.forward(xd).clone()                            # 40 instances
+    for j in (0, 7, 19):
+        alone = eng.forward(xd[j:j + 1].contiguous())         # 2 instances: the split-K regime of the default mode
+        assert torch.equal(alone[:, 0], full[:, j]), "tile %d alone differs from the tile inside the batch" % j
+    part = torch.zeros_like(full)
+    eng.forward_stems(xd, part, 1, 1)
+    eng.forward_stems(xd, part, 0, 1)
+    assert torch.equal(part, full)
+    three = eng.forward(xd[3:6].contiguous())                 # another batch size, other slots
+    assert torch.equal(three, full[:, 3:6])
+    ks = _layer_kernels(eng, xd[0:1].contiguous())
+    assert all(ks[n].startswith("srt_dec_wino<") for n in ("up3", "up4", "up5")), ks     # geometry decides, not the batch
+    _check_taps(eng, oracle, coeffs(1), x[7], 0, 1, 7, full.cpu().numpy(), "batch-invariant")
+    # audio: chunked == one batch up to the overlap-add association at the chunk seams only
+    n = 4096 * 70 + 8192 + 700
+    L, R = oracle.synth_audio(n, 99, True)
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    small = _engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=2, batch_invariant=True)
+    for s in range(2):
+        small.set_coeff(s, coeffs(s))
+    ref = eng.separate(Ld, Rd).cpu().numpy()
+    got = stream.stitch(stream.separate_stream(small, Ld, Rd, 0, 1), n, 2)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    got2 = small.separate_host_stream(L, R)
+    assert np.abs(got2 - ref).max() <= 2e-6 * np.abs(ref).max()
+    eng.close(); small.close()
 
 
 def test_small_batch_split_k_and_graph_replay(oracle, coeffs):
