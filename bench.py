@@ -44,6 +44,17 @@ assert sum(LAYER_FLOP.values()) == FLOP_PER_PIXEL * T * F
 WINO_EXECUTED_FRACTION = 0.49
 
 
+def same_kernel(a, b):
+    """kernel symbols that differ only by trailing template arguments (mode flags appended as the code grows, at their defaults in the
+    older name): same base name and one argument list is a prefix of the other"""
+    def split(sym):
+        base, _, args = sym.partition("<")
+        return base.strip(), [x.strip() for x in args.rstrip("> ").split(",")] if args else []
+    (ba, aa), (bb, ab) = split(a), split(b)
+    n = min(len(aa), len(ab))
+    return ba == bb and aa[:n] == ab[:n]
+
+
 def executed_fraction(symbol):
     return WINO_EXECUTED_FRACTION if "wino" in symbol else 1.0
 
@@ -250,12 +261,10 @@ def main():
         dom_exec = executed_fraction(dom)
         dom_tflops = dom_alg_tflops * dom_exec                # what the matrix pipe executes: the roofline figure
         traffic = mfma_busy = pmc_file = None
-        def _norm(sym):                                     # kernel symbol without its trailing mode flags (they grow with the code)
-            return ",".join(sym.split(",")[:8])
         for pf in PMC_SUMMARIES:
             try:
                 allpm = json.load(open(pf))
-                pm = allpm.get(dom) or next((v for k, v in allpm.items() if _norm(k) == _norm(dom)), None)
+                pm = allpm.get(dom) or next((v for k, v in allpm.items() if same_kernel(k, dom)), None)
                 if pm and a.tiles == TILES:
                     traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
                     # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs; 64 per v_mfma_f32_32x32x2_f32)

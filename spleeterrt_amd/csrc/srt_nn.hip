@@ -577,8 +577,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // with its loads drops to 0.02 ms); the fp16 values are used as they are, the weights are rounded to fp16 (exact for the
 // reference's fp16 model container), accumulation and the epilogue stay fp32.
 typedef _Float16 srt_h8 __attribute__((ext_vector_type(8)));
-template <int TH, int TW, int CIN, bool IN16 = false>
-__global__ void __launch_bounds__(256, 2) srt_up6_kernel(const SrtConvParams p)
+template <int TH, int TW, int CIN, bool IN16 = false, int OCC = 2>     // OCC: workgroups per CU the register budget is held to (the LDS tile must fit as often)
+__global__ void __launch_bounds__(256, OCC) srt_up6_kernel(const SrtConvParams p)
 {
     static_assert(!IN16 || CIN == 32, "the fp16 form is written for two 16-channel k-groups");
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NSUB = (NPIX + 31) / 32, NPAD = NSUB * 32;
@@ -744,8 +744,15 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 5) UP6_LAUNCH(8, 32);
         else if (v == 3) UP6_LAUNCH(4, 64);
         else if (v == 4) UP6_LAUNCH(4, 128);
+#define UP6_LAUNCH_OCC(TH, TW, OCC) SRT_LAUNCH((srt_up6_kernel<TH, TW, 32, false, OCC>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.nstems * p.ntiles), dim3(256), 0, s, p)
+        else if (v == 6) UP6_LAUNCH_OCC(8, 32, 4);          // 35 KB of LDS per workgroup: four per CU
+        else if (v == 7) UP6_LAUNCH_OCC(4, 64, 3);          // 42 KB: three per CU
+        else if (v == 8) UP6_LAUNCH_OCC(8, 32, 3);
+        else if (v == 9) UP6_LAUNCH_OCC(16, 16, 4);         // 18 x 18 = 324 pixels: 11 sub-tiles, 35 KB
+#undef UP6_LAUNCH_OCC
 #endif
-        if (v == 0 && p.in16) SRT_LAUNCH((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
+        if (v > 5) {}
+        else if (v == 0 && p.in16) SRT_LAUNCH((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
         else if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -1;

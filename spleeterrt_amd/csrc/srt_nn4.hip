@@ -166,9 +166,14 @@ template <int N> struct WinoFor<N, N> { template <class F> static __device__ __f
 // All DMA is issued from inline assembly: the compiler's own bookkeeping of LDS-DMA makes every later LDS read wait for vmcnt(0),
 // i.e. for the pieces just issued.  Arrival is synchronised by hand: s_waitcnt vmcnt(n) + the K step's one barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <int BA, int BB, int NI, int ABL = 0>   // ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
+// s_waitcnt immediate for "at most n vector-memory operations outstanding" (gfx9 encoding: vmcnt = bits [15:14] : [3:0]; expcnt / lgkmcnt not waited for)
+constexpr int wino_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+// UR = depth of the two LDS rings: U slab k lives in buffer k % UR and is issued UR - 1 K steps before its use, patch k in slot k % UR,
+// issued UR - 1 steps before the step that reads it (UR = 3 was the round-2 kernel).
+template <int BA, int BB, int NI, int ABL = 0, int UR = 3, int SB = 0>   // SB 1: a quad's VALU work fenced behind its MFMAs (see srt_dec_wino32); ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
 __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
+    static_assert(UR >= 3 && UR <= 6, "ring depth");
     static_assert(BA * BB * NI == 64 && (BA * BB) % 16 == 0, "tile");
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
     constexpr int TH = 2 * BA, TW = 2 * BB;
@@ -176,9 +181,9 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     constexpr int PCH = NI * PH * PROW;                                      // floats per channel
     constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4s (4 channels), DMA pieces and floats per patch buffer
     constexpr int PPW = (NPP + 7) / 8;                                       // patch pieces per wave
-    __shared__ __attribute__((aligned(16))) float s_all[3 * UBUF + 3 * PBUF];
+    __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
     float* s_u = s_all;
-    float* s_p = s_all + 3 * UBUF;
+    float* s_p = s_all + UR * UBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
     const float* pa; const float* pb;                                        // wave-uniform: channel 0 of the unit's first instance
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(3 * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(UR * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
     auto set_dma_unit = [&](int unit) {
         const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
 #pragma unroll
@@ -285,15 +290,14 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         // patch k+1 (a VALU write to a register that an MFMA issued just before still reads as its B operand has to wait for it).
         // Quad 0 first refills the last quad's points from the OLD row transforms, then reads its patch (k+1) and transforms the rows.
         float v[NP];
-        auto issue_first = [&]() {                                           // U slabs 0, 1 -> buffers 0, 1; patches 0, 1 -> slots 0, 1 of the unit set by set_dma_unit
+        auto issue_first = [&]() {                                           // U slabs 0..UR-2 -> buffers 0..UR-2; patches 0..UR-2 -> slots 0..UR-2 of the unit set by set_dma_unit
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma_u(0, 0, i);
+            for (int j = 0; j < UR - 1; ++j) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma_u(min(1, nk - 1), 1, i);
+                for (int i = 0; i < 2; ++i) dma_u(min(j, nk - 1), j, i);
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) dma_patch(0, 0, i);
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) dma_patch(min(1, nk - 1), 1, i);
+                for (int i = 0; i < PPW; ++i) dma_patch(min(j, nk - 1), j, i);
+            }
         };
         set_dma_unit(unit0);
         issue_first();
@@ -308,17 +312,17 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
         WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_patch(min(2, nk - 1), 2, i);
-        int slot = 0;                                                        // k % 3: U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+3 goes to `slot`
+        for (int i = 0; i < PPW; ++i) dma_patch(min(UR - 1, nk - 1), UR - 1, i);
+        int slot = 0;                                                        // k % UR: U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+UR goes to `slot`
         for (int k = 0; k < nk; ++k) {
-            // vmcnt(2 + PPW): everything older than this wave's pieces of U slab k+1 and patch k+2 (issued in step k-1) has landed - its
-            // pieces of U slab k and of patch k+1.  After the barrier so have everyone's, and every wave is done with step k-1: U buffer
-            // (k+2)%3 and patch slot k%3 are free.
-            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(0x0F70 | (2 + PPW)); __syncthreads(); }
-            const int kd = min(k + 2, nk - 1), kp = min(k + 3, nk - 1);      // (past the end: refill with the last slab / patch, unused)
-            const int ubn = slot == 0 ? 2 : slot - 1;                        // (k + 2) % 3
+            // vmcnt((UR-2)(2 + PPW)): everything older than this wave's pieces of the last UR-2 steps has landed - its pieces of U slab k
+            // and of patch k+1 (both issued in step k+1-UR).  After the barrier so have everyone's, and every wave is done with step k-1:
+            // U buffer (k-1)%UR and patch slot k%UR are free.
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((UR - 2) * (2 + PPW))); __syncthreads(); }
+            const int kd = min(k + UR - 1, nk - 1), kp = min(k + UR, nk - 1);      // (past the end: refill with the last slab / patch, unused)
+            const int ubn = slot == 0 ? UR - 1 : slot - 1;                   // (k + UR - 1) % UR
             const float* ub = s_u + slot * UBUF + aoff + X0;
-            const float* pbuf = s_p + (slot == 2 ? 0 : slot + 1) * PBUF;
+            const float* pbuf = s_p + (slot == UR - 1 ? 0 : slot + 1) * PBUF;
             float4 a0 = *reinterpret_cast<const float4*>(ub), a1 = *reinterpret_cast<const float4*>(ub + 4);
             __builtin_amdgcn_sched_barrier(0);
             WinoFor<0, NQ>::run([&](auto qc) {
@@ -338,6 +342,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                     acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
                     acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
                 }
+                if constexpr (SB == 1) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ABL != 4) {
                     if constexpr (q == 0) {
                         constexpr int l0 = 4 * (NQ - 1);                     // the last quad's points, from the old row transforms
@@ -355,7 +360,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                 }
                 __builtin_amdgcn_sched_barrier(0);                           // quads stay in order: bounded live ranges, no accumulator copies
             });
-            slot = slot == 2 ? 0 : slot + 1;
+            slot = slot == UR - 1 ? 0 : slot + 1;
         }
 
         // ---- the next unit's first DMA goes out before this unit's epilogue.  Barrier: every wave is out of the K loop, so the U
@@ -396,6 +401,286 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     };
     if (h) body(std::integral_constant<int, 1>{});
     else body(std::integral_constant<int, 0>{});
+}
+
+// ------------------------------------------------------------------------------------------- 32 output channels per workgroup
+// Round 3.  The fp32 MFMA and ordinary VALU instructions share one ALU on gfx950 (scripts/ubench/mfma_valu.hip: beside
+// v_mfma_f32_16x16x4_f32 every v_add costs its full 4 cycles and the first one after an MFMA ~10 more, with one or two waves per SIMD;
+// beside a bf16 MFMA the same instructions are free), so the kernel above pays its ~116 transform instructions per 49 MFMAs in
+// matrix time.  Here a lane's transformed patch V feeds TWO MFMAs - the same block against two 16-channel M blocks - which halves the
+// transform work per MFMA, and the accumulators are split over the waves by parity CLASS instead of row parity, so no row transform is
+// computed twice:
+//
+//   workgroup = 32 output channels x 32 blocks (BA x BB blocks = 2 BA x 2 BB input pixels of ONE instance), 8 waves
+//   wave (g, CLS): block group g (16 blocks) x class CLS x both M blocks: 2 x {16, 12, 12, 9} accumulator tiles (128 / 96 / 96 / 72 registers)
+//   SIMD s holds waves s and s + 4: (g, C11) with (g, C00) on SIMDs 0-1 (50 MFMAs per K step), (g, C10) with (g, C01) on SIMDs 2-3 (48)
+//
+// Per K step a wave issues its points in quads: 8 MFMAs (4 points x 2 M blocks), then ONE burst of VALU work (4 points of the next
+// step, in quad 1 also the row transforms of the next patch): a transition between matrix and vector work per 8 MFMAs instead of per 4.
+// Global memory reaches the CU by LDS-DMA as above: per K step the 26 KiB U slab of the two M blocks (26 pieces) and the 4-channel
+// patch (4 pieces for 4 x 32 input pixels), four DMA instructions per wave; the input patch is now fetched once per 32 output channels.
+// The two x-parity classes of an output row live in different waves, so a lane stores single floats (each class owns every second
+// column); the four stores that complete a 16-byte segment are issued within the same epilogue and merge in L2.
+// Rings: U slab k lives in buffer k % UR, patch k in slot k % UR; both are issued D K steps before the step that uses them (slab k+D and
+// patch k+1+D during step k) and the workgroup meets at a barrier every BPS K steps (UR >= D + BPS keeps a DMA from overwriting what a
+// slower wave may still read).  Round-2 arrangement: UR = 3, D = 2, BPS = 1.
+// SB 1: the VALU work of a quad is fenced behind its MFMAs (clean bursts).  EA 1: the A operands of the first two quads of step k+1 are read
+// during the last two quads of step k, ahead of the barrier (slab k+1 is then waited for one barrier earlier), so no wave starts a step by
+// waiting for LDS.
+template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0>
+__global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
+{
+    static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS, "rings (5 x 30 KiB = 150 KiB of LDS)");
+    static_assert(BA * BB == 32 && BB % 16 == 0 || BA * BB == 32, "tile");
+    constexpr int UB1 = 4 * 16 * WINO_LD;                                    // one M block: 3328 floats = 13 pieces
+    constexpr int UBUF = 2 * UB1, NUP = 26;                                  // two M blocks (consecutive in the packed layout)
+    constexpr int TH = 2 * BA, TW = 2 * BB;
+    constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;
+    constexpr int PCH = PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
+    constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;                // DMA pieces per K step, per wave (the tail repeats the last piece)
+    __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
+    float* s_u = s_all;
+    float* s_p = s_all + UR * UBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int flags = tpw >> 8;                                              // (tuning aid) bit 0: static priority 1 for waves 4-7, the younger half of each SIMD pair
+    tpw &= 255;
+    if ((flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const int simd = wave & 3, hi = wave >> 2, g = simd & 1;                 // block group; class: SIMDs 0-1 C11 | C00, SIMDs 2-3 C10 | C01
+    const int cls = (simd >> 1) == 0 ? (hi ? 3 : 0) : (hi ? 2 : 1);
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
+    const int MB2 = p.Cout / 32, MB = p.Cout / 16;
+    const int nsp = tilesX * tilesY, upw = nsp * p.ntiles / tpw;             // workgroups per (stem, M-block pair)
+    const int pos = srt_xcd_order(upw * MB2 * p.nstems);
+    const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
+    const int m0 = mblk2 * 32;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const float* up = U + stem * u_stem + (size_t)(2 * mblk2) * UB1;         // K step k at + k * MB * UB1
+
+    const int blk = g * 16 + l15, ba = blk / BB, bb = blk % BB;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
+
+    // ---- DMA pieces of a K step: 0..25 the U slab, 26.. the patch.  Wave w moves pieces w, w + 8, ... (DPW of them; past the end: the last one
+    // again).  All but a wave's LAST piece are U pieces for every wave (global_load_lds); the last one is a U piece for waves 0-1 and a patch
+    // piece for the rest: ONE buffer_load ... lds whose descriptor, offsets and destination are picked by scalar selects on the wave-uniform
+    // `last_patch`, so the K loop has no branch around its DMA (a branchy version of the same loop measured 8 % slower).
+    static_assert(NUP >= 8 * (DPW - 1) && NUP < 8 * DPW, "piece map");
+    const bool last_patch = wave >= NUP - 8 * (DPW - 1);                     // wave-uniform
+    unsigned dvoff[DPW - 1], dm0[DPW - 1];
+#pragma unroll
+    for (int i = 0; i < DPW - 1; ++i) {
+        dvoff[i] = (unsigned)((wave + 8 * i) * 1024 + lane * 16);            // byte offset inside the slab
+        dm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wave + 8 * i) * 1024));
+    }
+    const int lpiece = min(wave + 8 * (DPW - 1), NPIECE - 1);                // the last ("flex") piece
+    const unsigned fm0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(last_patch ? UR * UBUF * 4 + (lpiece - NUP) * 1024 : lpiece * 1024));
+    constexpr unsigned OOR = 0x80000000u;
+    const unsigned nrec = last_patch ? (unsigned)min((size_t)0x7fffffff, (size_t)4 * p.srcA_tile) : 0x7fffffffu;
+    const float* pa; const float* pb;
+    unsigned fvoff;                                                          // flex piece: offset inside the instance (patch) or inside the slab (U)
+    auto set_dma_unit = [&](int unit) {
+        const int sp = unit % nsp, tile0 = unit / nsp, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+        const int e = (lpiece - NUP) * 64 + lane;
+        const int j = e % PR4, row = (e / PR4) % PH, c = e / (PR4 * PH);
+        const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
+        const bool ok = e >= 0 && e < NF4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const unsigned pvoff = ok ? 4u * (unsigned)((size_t)c * hw + (size_t)gy * p.W + gx) : OOR;
+        fvoff = last_patch ? pvoff : (unsigned)(lpiece * 1024 + lane * 16);
+        // descriptor base of the flex piece: the instance's source tensors (patch piece) or the U slab (64-bit selects on a uniform condition
+        // come out of the compiler as vector selects, which an "s" asm operand cannot take: select the halves and pin them to SGPRs)
+        const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile), bu_ = (size_t)up;
+        const unsigned alo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)ba_ : (unsigned)bu_), ahi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(ba_ >> 32) : (unsigned)(bu_ >> 32));
+        const unsigned blo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)bb_ : (unsigned)bu_), bhi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(bb_ >> 32) : (unsigned)(bu_ >> 32));
+        pa = (const float*)(((size_t)ahi << 32) | alo);
+        pb = (const float*)(((size_t)bhi << 32) | blo);
+    };
+    const int kA = p.CA / 4;
+    const unsigned kstep_bytes = (unsigned)(16 * hw), ustep_bytes = (unsigned)((size_t)MB * UB1 * 4);
+    auto dma_u = [&](int i, int ku, int ubuf) {
+        const float* src = up + (size_t)ku * MB * UB1;
+        const unsigned dst = dm0[i] + (unsigned)ubuf * (unsigned)(UBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
+    };
+    auto dma_flex = [&](int ku, int ubuf, int kp, int pslot) {              // U slab ku -> buffer ubuf (waves 0-1) | patch kp -> slot pslot
+        const bool fromA = kp < kA;
+        const size_t base = (size_t)(fromA ? pa : pb);                       // (both are the U slab for waves 0-1)
+        i32x4 rs;
+        rs.x = (int)(unsigned)(base & 0xffffffffu); rs.y = (int)(unsigned)((base >> 32) & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
+        const unsigned soff = last_patch ? (unsigned)(fromA ? kp : kp - kA) * kstep_bytes : (unsigned)ku * ustep_bytes;
+        const unsigned dst = fm0 + (last_patch ? (unsigned)pslot * (unsigned)(PBUF * 4) : (unsigned)ubuf * (unsigned)(UBUF * 4));
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(fvoff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+    };
+    // piece i of this wave
+    auto dma = [&](int i, int ku, int ubuf, int kp, int pslot) {
+        if (i == DPW - 1) dma_flex(ku, ubuf, kp, pslot);
+        else dma_u(i, ku, ubuf);
+    };
+    const int poff = (kq * PH + 2 * ba) * PROW + 2 * bb + 3;                 // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
+    const int aoff = (kq * 16 + l15) * WINO_LD;
+    const int nk = p.Cin / 4;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float* obase; bool blk_ok;
+    auto set_out_unit = [&](int unit) {
+        const int sp = unit % nsp, tile = unit / nsp, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
+        blk_ok = a0 < p.H && b0 < p.W;
+        obase = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
+    };
+
+    auto body = [&](auto cc) {
+        constexpr int CLS = decltype(cc)::value;
+        constexpr int X0 = CLS == 0 ? WINO_C11 : CLS == 1 ? WINO_C10 : CLS == 2 ? WINO_C01 : WINO_C00;
+        constexpr bool Y3 = CLS < 2, X3 = !(CLS & 1);
+        constexpr int NY = Y3 ? 4 : 3, NX = X3 ? 4 : 3, NP = NY * NX, NQ = (NP + 3) / 4, NROW = Y3 ? 4 : 3;
+        constexpr int PY = CLS < 2 ? 1 : 0, PX = X3 ? 1 : 0;
+        f32x4 acc[2][NP];
+        float t3[4][4], t2[4][3];
+        float2 xm[4]; float xa[4], xb[4];                                    // patch row r: columns (b0, b0+1) | b0-1 | b0+2 (3-tap classes only)
+        auto read_row = [&](const float* pbuf, int r) {
+            const float* q = pbuf + poff + r * PROW;
+            xm[r] = *reinterpret_cast<const float2*>(q + 1);
+            xa[r] = q[0];
+            if constexpr (X3) xb[r] = q[3];
+        };
+        auto rows = [&](int r) {
+            if constexpr (X3) wino_in3(xa[r], xm[r].x, xm[r].y, xb[r], t3[r]);
+            else wino_in2(xa[r], xm[r].x, xm[r].y, t2[r]);
+        };
+        float v[NP];
+        auto issue_first = [&]() {                                           // U slabs 0..D-1 -> buffers 0..D-1; patches 0..D-1 -> slots 0..D-1
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int i = 0; i < DPW; ++i) dma(i, min(j, nk - 1), j, min(j, nk - 1), j);
+        };
+        // K step k: U slab k in buffer su (= k % UR), patch k+1 in slot sp1; issues U slab k+D -> buffer sd and patch k+1+D -> slot sd1
+        float4 a0[2], a1[2];                                                 // A operands of the next two quads (EA: carried across K steps)
+        auto kstep = [&](int k, int su, int sp1, int sd, int sd1) __attribute__((always_inline)) {
+            const int kd = min(k + D, nk - 1), kp = min(k + 1 + D, nk - 1);  // (past the end: the last slab / patch again, unused)
+            const float* ub = s_u + su * UBUF + aoff + X0;
+            const float* ubx = s_u + (su == UR - 1 ? 0 : su + 1) * UBUF + aoff + X0;       // slab k+1 (EA)
+            const float* pbuf = s_p + sp1 * PBUF;
+            if (!EA || k == 0) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) { a0[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1); a1[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1 + 4); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WinoFor<0, NQ>::run([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int nm = (4 * q + 4 <= NP) ? 4 : NP - 4 * q;       // points of this quad
+                float4 a[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    a[mb] = a0[mb];
+                    if constexpr (EA && q == NQ - 1) a0[mb] = *reinterpret_cast<const float4*>(ubx + mb * UB1);            // next step, quad 0
+                    else a0[mb] = a1[mb];
+                    if constexpr (q + 2 < NQ && ABL != 5) a1[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1 + 4 * (q + 2));
+                    else if constexpr (EA && q == NQ - 2) a1[mb] = *reinterpret_cast<const float4*>(ubx + mb * UB1 + 4);  // next step, quad 1
+                }
+                if constexpr (ABL != 3) {                                    // DMA spread over the quads (NQ is 3 or 4, DPW 4)
+#pragma unroll
+                    for (int i = 0; i < DPW; ++i) if (i * NQ / DPW == q) dma(i, kd, sd, kp, sd1);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], acc[mb][4 * q], 0, 0, 0);
+                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], acc[mb][4 * q + 1], 0, 0, 0);
+                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], acc[mb][4 * q + 2], 0, 0, 0);
+                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], acc[mb][4 * q + 3], 0, 0, 0);
+                }
+                // one VALU instruction between two MFMAs of a wave costs about twice what it costs inside a burst (scripts/ubench/mfma_valu.hip:
+                // +26 % against +13 % at one VALU per MFMA): keep the quad's vector work behind its eight MFMAs instead of letting the
+                // scheduler interleave the two
+                if constexpr (SB == 1) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL != 4) {
+                    if constexpr (q == 0) {
+                        constexpr int l0 = 4 * (NQ - 1);                     // the last quad's points of THIS step, from the old row transforms
+                        WinoFor<l0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+#pragma unroll
+                        for (int r = 0; r < NROW; ++r) read_row(pbuf, r);    // patch k+1: lands in registers under quad 1's MFMAs
+                    } else {
+                        if constexpr (q == 1) {
+#pragma unroll
+                            for (int r = 0; r < NROW; ++r) rows(r);
+                        }
+                        WinoFor<4 * q - 4, 4 * q>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        set_dma_unit(unit0);
+        issue_first();
+        for (int t = 0; t < tpw; ++t) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int x = 0; x < NP; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
+        WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+        // patch D -> slot D % UR: the patch piece only (waves whose flex piece is one).  From here on every wave issues exactly DPW DMA
+        // instructions per K step, which is what the vmcnt arithmetic below counts on.
+        if (last_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
+        int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;           // k % UR, (k+1) % UR, (k+D) % UR, (k+1+D) % UR
+        for (int k = 0; k < nk; k += BPS) {
+            // vmcnt((D-BPS) DPW): everything older than the pieces of this wave's last D-BPS steps has landed: U slabs up to k+BPS-1 and patches up
+            // to k+BPS (issued in step k+BPS-1-D).  After the barrier so have everyone's, and every wave has finished step k-1.
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - BPS - EA) * DPW)); __syncthreads(); }
+#pragma unroll
+            for (int b = 0; b < BPS; ++b) {
+                if (BPS == 1 || k + b < nk) kstep(k + b, su, sp1, sd, sd1);
+                su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
+            }
+        }
+        if (t + 1 < tpw) {
+            __syncthreads();
+            set_dma_unit(unit0 + t + 1);
+            issue_first();
+        }
+        // ---- output transform + bias -> activation -> batch-norm: this lane's block, class (PY, PX), channels m0 + 16 mb + 4 kq + r
+        set_out_unit(unit0 + t);
+        auto emit = [&](auto act) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float bi[4], sc[4], sf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t ci = stem * p.coeff_stem + m0 + 16 * mb + 4 * kq + r;
+                    bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float m[NP];
+#pragma unroll
+                    for (int x = 0; x < NP; ++x) m[x] = acc[mb][x][r];
+                    float y[2][2];
+                    wino_out2d<NY, NX>(m, y);
+                    float* oc = obase + (size_t)(m0 + 16 * mb + 4 * kq + r) * ohw + (size_t)PY * Wo + PX;
+#pragma unroll
+                    for (int da = 0; da < 2; ++da)
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) oc[(size_t)(2 * da) * Wo + 2 * db] = act(y[da][db], bi[r], sc[r], sf[r]);
+                }
+            }
+        };
+        if (blk_ok) {
+            if (srt_act_is_plain_elu(actp)) emit([&](float y, float b, float s, float f) { return srt_dec_epilogue_elu(y, b, s, f); });
+            else if (actp.ue != 0.0f) emit([&](float y, float b, float s, float f) { return srt_dec_epilogue(y, b, s, f, actp); });
+            else emit([&](float y, float b, float s, float f) { return srt_dec_epilogue_lin(y, b, s, f, actp.lin); });
+        }
+        }                                                                    // units
+    };
+    if (cls == 0) body(std::integral_constant<int, 0>{});
+    else if (cls == 1) body(std::integral_constant<int, 1>{});
+    else if (cls == 2) body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 3>{});
 }
 
 // ------------------------------------------------------------------------------------------- launcher
@@ -440,10 +725,56 @@ static int wino_tpw(long wgs, long units)
     while (tpw < 8 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
     return tpw;
 }
+// layers with at least 32 output channels: the 32-channel workgroup (srt_dec_wino32).  SRT_TUNE=wino32=0|1 overrides in tuning builds.
+#ifndef SRT_WINO32_DEFAULT
+#define SRT_WINO32_DEFAULT 0
+#endif
+#ifndef SRT_WINO32_RING
+#define SRT_WINO32_RING 3
+#endif
+#ifndef SRT_WINO_RING
+#define SRT_WINO_RING 3
+#endif
+static int wino32_on()
+{
+#ifdef SRT_TUNING
+    const int v = wino_tune("wino32=");
+    if (v >= 0) return v;
+#endif
+    return SRT_WINO32_DEFAULT;
+}
 int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
 {
     if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 3)) return 1;
     const int MB = p.Cout / 16;
+    if (p.Cout % 32 == 0 && p.H >= 4 && p.W >= 32 && wino32_on()) {
+        const long units = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
+        int tpw = wino_tpw(wgs, units);
+        const dim3 grid((unsigned)(wgs / tpw));
+#ifdef SRT_TUNING
+        if (wino_tune("winoprio=") > 0) tpw |= 256;
+        switch (wino_tune("winoabl=")) {
+        case 1: SRT_LAUNCH((srt_dec_wino32<2, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 3: SRT_LAUNCH((srt_dec_wino32<2, 16, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 4: SRT_LAUNCH((srt_dec_wino32<2, 16, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 5: SRT_LAUNCH((srt_dec_wino32<2, 16, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        }
+        if (wino_tune("winosb=") == 1) {
+            if (wino_tune("winoring=") == 52) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+            else if (wino_tune("winoea=") == 1) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4, 3, 1, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+            else if (wino_tune("winoea=") == 2) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+            else SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 3, 2, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+            return 0;
+        }
+        switch (wino_tune("winoring=")) {                                    // rings: <UR, D, BPS>
+        case 4: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 42: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4, 2, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 52: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        }
+#endif
+        SRT_LAUNCH((srt_dec_wino32<2, 16, 0, SRT_WINO32_RING>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (p.H >= 8 && p.W >= 32) {
         const long units = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * p.ntiles, wgs = units * MB * p.nstems;
         const int tpw = wino_tpw(wgs, units);
@@ -456,8 +787,14 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         }
+        if (wino_tune("winosb=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
+        switch (wino_tune("winoring=")) {
+        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 6: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 6>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        }
 #endif
-        SRT_LAUNCH((srt_dec_wino<4, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, SRT_WINO_RING>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
     } else if (p.H >= 4 && p.W >= 16) {
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 3) / 4), wgs = units * MB * p.nstems;
         const int tpw = wino_tpw(wgs, units);
