@@ -170,7 +170,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int wino_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // UR = depth of the two LDS rings: U slab k lives in buffer k % UR and is issued UR - 1 K steps before its use, patch k in slot k % UR,
 // issued UR - 1 steps before the step that reads it (UR = 3 was the round-2 kernel).
-template <int BA, int BB, int NI, int ABL = 0, int UR = 3, int SB = 0>   // SB 1: a quad's VALU work fenced behind its MFMAs (see srt_dec_wino32); ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
+// CS 1: the units of a workgroup run as ONE stream of K steps (see srt_dec_wino32): no per-unit DMA drain, barrier or separate first transform.
+template <int BA, int BB, int NI, int ABL = 0, int UR = 3, int SB = 0, int CS = 0>   // SB 1: a quad's VALU work fenced behind its MFMAs (see srt_dec_wino32); ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
 __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(UR >= 3 && UR <= 6, "ring depth");
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     unsigned pvoff[PPW], pm0[PPW];
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile);
     const float* pa; const float* pb;                                        // wave-uniform: channel 0 of the unit's first instance
+    unsigned n_pvoff[PPW]; const float* n_pa; const float* n_pb;             // CS: the same for the workgroup's next unit
 #pragma unroll
     for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(UR * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
     auto set_dma_unit = [&](int unit) {
@@ -237,6 +239,27 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         }
         pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;
         pb = p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile;
+    };
+    auto dma_keep_as_next = [&]() {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) n_pvoff[i] = pvoff[i];
+        n_pa = pa; n_pb = pb;
+    };
+    auto dma_advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) pvoff[i] = n_pvoff[i];
+        pa = n_pa; pb = n_pb;
+    };
+    // the DMA state of unit `unit` into the "next" slot (the current one is saved around the computation)
+    auto set_dma_next = [&](int unit) {
+        unsigned keep[PPW]; const float* ka = pa; const float* kb = pb;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) keep[i] = pvoff[i];
+        set_dma_unit(unit);
+        dma_keep_as_next();
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) pvoff[i] = keep[i];
+        pa = ka; pb = kb;
     };
     const int kA = p.CA / 4;                                                 // K steps [0, kA) read srcA, the rest srcB (CA % 4 == 0)
     const unsigned kstep_bytes = (unsigned)(16 * hw);                        // 4 channels
@@ -300,26 +323,36 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
             }
         };
         set_dma_unit(unit0);
+        if (CS) { if (tpw > 1) set_dma_next(unit0 + 1); else dma_keep_as_next(); }
         issue_first();
-        for (int t = 0; t < tpw; ++t) {
 #pragma unroll
         for (int x = 0; x < NP; ++x)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the unit's first slab and patches (and whatever the previous unit left in flight)
-        __syncthreads();
+        int slot = 0;                                                        // k % UR (CS: of the running step count): U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+UR goes to `slot`
+        auto unit_prologue = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): the unit's first slab and patches (and whatever the previous unit left in flight)
+            __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
-        WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+            for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
+            WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_patch(min(UR - 1, nk - 1), UR - 1, i);
-        int slot = 0;                                                        // k % UR: U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+UR goes to `slot`
+            for (int i = 0; i < PPW; ++i) dma_patch(min(UR - 1, nk - 1), UR - 1, i);
+            slot = 0;
+        };
+        if (CS) unit_prologue();
+        for (int t = 0; t < tpw; ++t) {
+        if (!CS) unit_prologue();
         for (int k = 0; k < nk; ++k) {
             // vmcnt((UR-2)(2 + PPW)): everything older than this wave's pieces of the last UR-2 steps has landed - its pieces of U slab k
             // and of patch k+1 (both issued in step k+1-UR).  After the barrier so have everyone's, and every wave is done with step k-1:
             // U buffer (k-1)%UR and patch slot k%UR are free.
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((UR - 2) * (2 + PPW))); __syncthreads(); }
-            const int kd = min(k + UR - 1, nk - 1), kp = min(k + UR, nk - 1);      // (past the end: refill with the last slab / patch, unused)
+            // past the end of the unit: CS - the first slabs / patches of the workgroup's next unit (the DMA state switches to it at the first step
+            // whose patch belongs to it; U does not depend on the unit); otherwise the last slab / patch again, unused
+            if (CS && k + UR == nk) dma_advance();
+            const int kd = CS ? (k + UR - 1 >= nk ? k + UR - 1 - nk : k + UR - 1) : min(k + UR - 1, nk - 1);
+            const int kp = CS ? (k + UR >= nk ? k + UR - nk : k + UR) : min(k + UR, nk - 1);
             const int ubn = slot == 0 ? UR - 1 : slot - 1;                   // (k + UR - 1) % UR
             const float* ub = s_u + slot * UBUF + aoff + X0;
             const float* pbuf = s_p + (slot == UR - 1 ? 0 : slot + 1) * PBUF;
@@ -366,7 +399,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         // ---- the next unit's first DMA goes out before this unit's epilogue.  Barrier: every wave is out of the K loop, so the U
         // buffers and patch slots are free (the refills the last K steps issued past the end target the same pieces from the same
         // waves, earlier in each wave's DMA order, so they land first).
-        if (t + 1 < tpw) {
+        if (!CS && t + 1 < tpw) {
             __syncthreads();
             set_dma_unit(unit0 + t + 1);
             issue_first();
@@ -396,6 +429,13 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
             if (srt_act_is_plain_elu(actp)) emit([&](float y, int r) { return srt_dec_epilogue_elu(y, bi[r], sc[r], sf[r]); });
             else if (actp.ue != 0.0f) emit([&](float y, int r) { return srt_dec_epilogue(y, bi[r], sc[r], sf[r], actp); });
             else emit([&](float y, int r) { return srt_dec_epilogue_lin(y, bi[r], sc[r], sf[r], actp.lin); });
+        }
+        if (t + 1 < tpw) {
+#pragma unroll
+            for (int x = 0; x < NP; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
+            if (CS && t + 2 < tpw) set_dma_next(unit0 + t + 2);              // (the DMA state itself moved on UR steps before the unit ended)
         }
         }                                                                    // units
     };
@@ -427,10 +467,16 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 // SB 1: the VALU work of a quad is fenced behind its MFMAs (clean bursts).  EA 1: the A operands of the first two quads of step k+1 are read
 // during the last two quads of step k, ahead of the barrier (slab k+1 is then waited for one barrier earlier), so no wave starts a step by
 // waiting for LDS.
-template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0>
+// ST 1: the two waves of a SIMD are staggered - the second one (classes C01 / C00) reads its patch rows right after the barrier and transforms them
+// behind its FIRST quad, the first one (C11 / C10) behind its second quad, so that one wave's long VALU burst meets the other's MFMAs
+// instead of the other's burst (the barrier starts both at the same point of the step every time).
+// CS 1: the units of a workgroup form ONE stream of K steps: the last D steps of a unit already fetch the first slabs / patches of the next
+// unit (instead of refetching the last ones as filler), and the next unit's first transformed patch comes out of the ordinary refills of the
+// last step, so a unit boundary is an epilogue and nothing else: no drained DMA queue, no extra barrier, no separate first transform.
+template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0>
 __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
-    static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS, "rings (5 x 30 KiB = 150 KiB of LDS)");
+    static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS && !(CS && EA), "rings (5 x 30 KiB = 150 KiB of LDS)");
     static_assert(BA * BB == 32 && BB % 16 == 0 || BA * BB == 32, "tile");
     constexpr int UB1 = 4 * 16 * WINO_LD;                                    // one M block: 3328 floats = 13 pieces
     constexpr int UBUF = 2 * UB1, NUP = 26;                                  // two M blocks (consecutive in the packed layout)
@@ -478,24 +524,32 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const unsigned fm0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(last_patch ? UR * UBUF * 4 + (lpiece - NUP) * 1024 : lpiece * 1024));
     constexpr unsigned OOR = 0x80000000u;
     const unsigned nrec = last_patch ? (unsigned)min((size_t)0x7fffffff, (size_t)4 * p.srcA_tile) : 0x7fffffffu;
-    const float* pa; const float* pb;
-    unsigned fvoff;                                                          // flex piece: offset inside the instance (patch) or inside the slab (U)
-    auto set_dma_unit = [&](int unit) {
-        const int sp = unit % nsp, tile0 = unit / nsp, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+    // per-unit DMA state of the flex piece: descriptor base halves (wave-uniform) and the lane's offset.  For waves 0-1 (U piece) the base is the
+    // U slab and the offset the lane's place in it, whatever the unit.  (64-bit selects on a uniform condition come out of the compiler as
+    // vector selects, which an "s" asm operand cannot take: the halves are selected and pinned to SGPRs.)
+    unsigned c_alo, c_ahi, c_blo, c_bhi, c_voff, n_alo, n_ahi, n_blo, n_bhi, n_voff;       // current / next unit
+    struct UnitBase { unsigned alo, ahi, blo, bhi; };                        // (uniform members only: with the per-lane offset in the same struct the compiler treats all of it as divergent)
+    auto unit_base = [&](int unit) {
+        const int tile0 = unit / nsp;
+        const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile), bu_ = (size_t)up;
+        UnitBase u;
+        u.alo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)ba_ : (unsigned)bu_); u.ahi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(ba_ >> 32) : (unsigned)(bu_ >> 32));
+        u.blo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)bb_ : (unsigned)bu_); u.bhi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(bb_ >> 32) : (unsigned)(bu_ >> 32));
+        return u;
+    };
+    auto unit_voff = [&](int unit) {
+        const int sp = unit % nsp, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
         const int e = (lpiece - NUP) * 64 + lane;
         const int j = e % PR4, row = (e / PR4) % PH, c = e / (PR4 * PH);
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
         const bool ok = e >= 0 && e < NF4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
         const unsigned pvoff = ok ? 4u * (unsigned)((size_t)c * hw + (size_t)gy * p.W + gx) : OOR;
-        fvoff = last_patch ? pvoff : (unsigned)(lpiece * 1024 + lane * 16);
-        // descriptor base of the flex piece: the instance's source tensors (patch piece) or the U slab (64-bit selects on a uniform condition
-        // come out of the compiler as vector selects, which an "s" asm operand cannot take: select the halves and pin them to SGPRs)
-        const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile), bu_ = (size_t)up;
-        const unsigned alo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)ba_ : (unsigned)bu_), ahi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(ba_ >> 32) : (unsigned)(bu_ >> 32));
-        const unsigned blo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)bb_ : (unsigned)bu_), bhi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(bb_ >> 32) : (unsigned)(bu_ >> 32));
-        pa = (const float*)(((size_t)ahi << 32) | alo);
-        pb = (const float*)(((size_t)bhi << 32) | blo);
+        return last_patch ? pvoff : (unsigned)(lpiece * 1024 + lane * 16);
     };
+    auto unit_cur = [&](int unit) { const UnitBase u = unit_base(unit); c_alo = u.alo; c_ahi = u.ahi; c_blo = u.blo; c_bhi = u.bhi; c_voff = unit_voff(unit); };
+    auto unit_nxt = [&](int unit) { const UnitBase u = unit_base(unit); n_alo = u.alo; n_ahi = u.ahi; n_blo = u.blo; n_bhi = u.bhi; n_voff = unit_voff(unit); };
+    auto unit_nxt_is_cur = [&]() { n_alo = c_alo; n_ahi = c_ahi; n_blo = c_blo; n_bhi = c_bhi; n_voff = c_voff; };
+    auto unit_advance = [&]() { c_alo = n_alo; c_ahi = n_ahi; c_blo = n_blo; c_bhi = n_bhi; c_voff = n_voff; };
     const int kA = p.CA / 4;
     const unsigned kstep_bytes = (unsigned)(16 * hw), ustep_bytes = (unsigned)((size_t)MB * UB1 * 4);
     auto dma_u = [&](int i, int ku, int ubuf) {
@@ -503,14 +557,16 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         const unsigned dst = dm0[i] + (unsigned)ubuf * (unsigned)(UBUF * 4);
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
     };
-    auto dma_flex = [&](int ku, int ubuf, int kp, int pslot) {              // U slab ku -> buffer ubuf (waves 0-1) | patch kp -> slot pslot
+    // U slab ku -> buffer ubuf (waves 0-1) | patch kp of the DMA state's unit -> slot pslot
+    auto dma_flex = [&](int ku, int ubuf, int kp, int pslot) {
         const bool fromA = kp < kA;
-        const size_t base = (size_t)(fromA ? pa : pb);                       // (both are the U slab for waves 0-1)
+        const unsigned lo = fromA ? c_alo : c_blo, hi = fromA ? c_ahi : c_bhi;       // (both are the U slab for waves 0-1)
         i32x4 rs;
-        rs.x = (int)(unsigned)(base & 0xffffffffu); rs.y = (int)(unsigned)((base >> 32) & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
+        rs.x = (int)lo; rs.y = (int)(hi & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
         const unsigned soff = last_patch ? (unsigned)(fromA ? kp : kp - kA) * kstep_bytes : (unsigned)ku * ustep_bytes;
         const unsigned dst = fm0 + (last_patch ? (unsigned)pslot * (unsigned)(PBUF * 4) : (unsigned)ubuf * (unsigned)(UBUF * 4));
-        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(fvoff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+        const unsigned voff = c_voff;
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(rs), "s"(dst), "s"(soff) : "memory");
     };
     // piece i of this wave
     auto dma = [&](int i, int ku, int ubuf, int kp, int pslot) {
@@ -529,12 +585,13 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         obase = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
     };
 
-    auto body = [&](auto cc) {
+    auto body = [&](auto cc) __attribute__((always_inline)) {
         constexpr int CLS = decltype(cc)::value;
         constexpr int X0 = CLS == 0 ? WINO_C11 : CLS == 1 ? WINO_C10 : CLS == 2 ? WINO_C01 : WINO_C00;
         constexpr bool Y3 = CLS < 2, X3 = !(CLS & 1);
         constexpr int NY = Y3 ? 4 : 3, NX = X3 ? 4 : 3, NP = NY * NX, NQ = (NP + 3) / 4, NROW = Y3 ? 4 : 3;
         constexpr int PY = CLS < 2 ? 1 : 0, PX = X3 ? 1 : 0;
+        constexpr int RQ = ((ST == 1 && CLS >= 2) || (ST == 2 && CLS < 2)) ? 0 : 1;                         // quad whose burst carries the row transforms
         f32x4 acc[2][NP];
         float t3[4][4], t2[4][3];
         float2 xm[4]; float xa[4], xb[4];                                    // patch row r: columns (b0, b0+1) | b0-1 | b0+2 (3-tap classes only)
@@ -558,13 +615,23 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         // K step k: U slab k in buffer su (= k % UR), patch k+1 in slot sp1; issues U slab k+D -> buffer sd and patch k+1+D -> slot sd1
         float4 a0[2], a1[2];                                                 // A operands of the next two quads (EA: carried across K steps)
         auto kstep = [&](int k, int su, int sp1, int sd, int sd1) __attribute__((always_inline)) {
-            const int kd = min(k + D, nk - 1), kp = min(k + 1 + D, nk - 1);  // (past the end: the last slab / patch again, unused)
+            // past the end of the unit: CS - the first slabs / patches of the workgroup's next unit (U does not depend on the unit; after the last unit the
+            // "next" state equals the current one: valid addresses, unused data); otherwise the last slab / patch again, unused
+            // (the DMA state - c_* - switches to the next unit at the first step whose patch belongs to it: a 4-way select between the two
+            //  states inside dma_flex turns into a dynamically indexed load from the lambda's closure, which then stays in scratch memory and
+            //  makes every wave-uniform value of the kernel a vector value)
+            if (CS && k + 1 + D == nk) unit_advance();
+            const int kd = CS ? (k + D >= nk ? k + D - nk : k + D) : min(k + D, nk - 1), kp = CS ? (k + 1 + D >= nk ? k + 1 + D - nk : k + 1 + D) : min(k + 1 + D, nk - 1);
             const float* ub = s_u + su * UBUF + aoff + X0;
             const float* ubx = s_u + (su == UR - 1 ? 0 : su + 1) * UBUF + aoff + X0;       // slab k+1 (EA)
             const float* pbuf = s_p + sp1 * PBUF;
             if (!EA || k == 0) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) { a0[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1); a1[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1 + 4); }
+            }
+            if constexpr (RQ == 0 && ABL != 4) {
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) read_row(pbuf, r);            // patch k+1 (landed before this step's barrier): in registers by the end of quad 0
             }
             __builtin_amdgcn_sched_barrier(0);
             WinoFor<0, NQ>::run([&](auto qc) {
@@ -598,10 +665,15 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
                     if constexpr (q == 0) {
                         constexpr int l0 = 4 * (NQ - 1);                     // the last quad's points of THIS step, from the old row transforms
                         WinoFor<l0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+                        if constexpr (RQ == 0) {
 #pragma unroll
-                        for (int r = 0; r < NROW; ++r) read_row(pbuf, r);    // patch k+1: lands in registers under quad 1's MFMAs
+                            for (int r = 0; r < NROW; ++r) rows(r);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NROW; ++r) read_row(pbuf, r);    // patch k+1: lands in registers under quad 1's MFMAs
+                        }
                     } else {
-                        if constexpr (q == 1) {
+                        if constexpr (q == 1 && RQ == 1) {
 #pragma unroll
                             for (int r = 0; r < NROW; ++r) rows(r);
                         }
@@ -611,24 +683,30 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
-        set_dma_unit(unit0);
+        unit_cur(unit0);
+        if (CS && tpw > 1) unit_nxt(unit0 + 1); else unit_nxt_is_cur();
         issue_first();
-        for (int t = 0; t < tpw; ++t) {
+        int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;           // k % UR, (k+1) % UR, (k+D) % UR, (k+1+D) % UR  (CS: of the running step count)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int x = 0; x < NP; ++x)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
-        __syncthreads();
+        auto unit_prologue = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+            __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
-        WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
-        // patch D -> slot D % UR: the patch piece only (waves whose flex piece is one).  From here on every wave issues exactly DPW DMA
-        // instructions per K step, which is what the vmcnt arithmetic below counts on.
-        if (last_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
-        int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;           // k % UR, (k+1) % UR, (k+D) % UR, (k+1+D) % UR
+            for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
+            WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+            // patch D -> slot D % UR: the patch piece only (waves whose flex piece is one).  From here on every wave issues exactly DPW DMA
+            // instructions per K step, which is what the vmcnt arithmetic below counts on.
+            if (last_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
+            su = 0; sp1 = 1 % UR; sd = D % UR; sd1 = (D + 1) % UR;
+        };
+        if (CS) unit_prologue();
+        for (int t = 0; t < tpw; ++t) {
+        if (!CS) unit_prologue();
         for (int k = 0; k < nk; k += BPS) {
             // vmcnt((D-BPS) DPW): everything older than the pieces of this wave's last D-BPS steps has landed: U slabs up to k+BPS-1 and patches up
             // to k+BPS (issued in step k+BPS-1-D).  After the barrier so have everyone's, and every wave has finished step k-1.
@@ -639,9 +717,10 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
                 su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
             }
         }
-        if (t + 1 < tpw) {
+        if (!CS && t + 1 < tpw) {
             __syncthreads();
-            set_dma_unit(unit0 + t + 1);
+            unit_cur(unit0 + t + 1);
+            unit_nxt_is_cur();
             issue_first();
         }
         // ---- output transform + bias -> activation -> batch-norm: this lane's block, class (PY, PX), channels m0 + 16 mb + 4 kq + r
@@ -674,6 +753,15 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
             if (srt_act_is_plain_elu(actp)) emit([&](float y, float b, float s, float f) { return srt_dec_epilogue_elu(y, b, s, f); });
             else if (actp.ue != 0.0f) emit([&](float y, float b, float s, float f) { return srt_dec_epilogue(y, b, s, f, actp); });
             else emit([&](float y, float b, float s, float f) { return srt_dec_epilogue_lin(y, b, s, f, actp.lin); });
+        }
+        if (t + 1 < tpw) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int x = 0; x < NP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+            if (CS && t + 2 < tpw) unit_nxt(unit0 + t + 2);                  // (the DMA state itself moved on D+1 steps before the unit ended; after the last unit it keeps valid addresses)
         }
         }                                                                    // units
     };
@@ -725,16 +813,14 @@ static int wino_tpw(long wgs, long units)
     while (tpw < 8 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
     return tpw;
 }
-// layers with at least 32 output channels: the 32-channel workgroup (srt_dec_wino32).  SRT_TUNE=wino32=0|1 overrides in tuning builds.
+// Layers with a multiple of 32 output channels (up2..up4) run the 32-channel workgroup, srt_dec_wino32, in the arrangement measured
+// fastest at 64 tiles x 4 stems: rings of three, fenced VALU bursts, staggered wave pairs, the units of a
+// workgroup as one continuous K stream.  SRT_TUNE=wino32=0|1 and winocfg=<n> select the other measured arrangements in tuning builds.
 #ifndef SRT_WINO32_DEFAULT
-#define SRT_WINO32_DEFAULT 0
+#define SRT_WINO32_DEFAULT 1
 #endif
-#ifndef SRT_WINO32_RING
-#define SRT_WINO32_RING 3
-#endif
-#ifndef SRT_WINO_RING
+#define SRT_WINO32_SHIPPED 2, 16, 0, 3, 2, 1, 1, 0, 1, 1
 #define SRT_WINO_RING 3
-#endif
 static int wino32_on()
 {
 #ifdef SRT_TUNING
@@ -753,26 +839,27 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const dim3 grid((unsigned)(wgs / tpw));
 #ifdef SRT_TUNING
         if (wino_tune("winoprio=") > 0) tpw |= 256;
-        switch (wino_tune("winoabl=")) {
-        case 1: SRT_LAUNCH((srt_dec_wino32<2, 16, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 3: SRT_LAUNCH((srt_dec_wino32<2, 16, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 4: SRT_LAUNCH((srt_dec_wino32<2, 16, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 5: SRT_LAUNCH((srt_dec_wino32<2, 16, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+#define W32(...) do { SRT_LAUNCH((srt_dec_wino32<2, 16, __VA_ARGS__>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; } while (0)
+        switch (wino_tune("winoabl=")) {                                     // ablations of the shipped arrangement (wrong results, timing only)
+        case 1: W32(1, 3, 2, 1, 1, 0, 1, 1);
+        case 3: W32(3, 3, 2, 1, 1, 0, 1, 1);
+        case 4: W32(4, 3, 2, 1, 1, 0, 1, 1);
+        case 5: W32(5, 3, 2, 1, 1, 0, 1, 1);
         }
-        if (wino_tune("winosb=") == 1) {
-            if (wino_tune("winoring=") == 52) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
-            else if (wino_tune("winoea=") == 1) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4, 3, 1, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
-            else if (wino_tune("winoea=") == 2) SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
-            else SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 3, 2, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
-            return 0;
+        switch (wino_tune("winocfg=")) {                                     // <ABL, UR, D, BPS, SB, EA, ST, CS>: arrangements measured on the way
+        case 1: W32(0, 3, 2, 1, 0, 0, 0);                                    // first version: compiler-interleaved VALU
+        case 2: W32(0, 3, 2, 1, 1, 0, 0);                                    // + fenced bursts
+        case 3: W32(0, 3, 2, 1, 1, 0, 1);                                    // + staggered pairs
+        case 4: W32(0, 5, 3, 2, 1, 0, 0);                                    // fenced bursts, barrier per two steps
+        case 5: W32(0, 4, 3, 1, 1, 1, 0);                                    // early A-operand reads
+        case 6: W32(0, 3, 2, 1, 1, 0, 2);                                    // stagger the other way round
+        case 7: W32(0, 5, 4, 1, 1, 0, 1);                                    // slabs four steps ahead
+        case 8: W32(0, 5, 3, 2, 1, 0, 1, 1);                                 // rings of 5, barrier per two steps, continuous K stream across units
+        case 10: W32(0, 5, 3, 2, 1, 0, 1, 0);                                // the same without the continuous stream
         }
-        switch (wino_tune("winoring=")) {                                    // rings: <UR, D, BPS>
-        case 4: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 42: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 4, 2, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 52: SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 5, 3, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        }
+#undef W32
 #endif
-        SRT_LAUNCH((srt_dec_wino32<2, 16, 0, SRT_WINO32_RING>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     if (p.H >= 8 && p.W >= 32) {
@@ -788,6 +875,8 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         }
         if (wino_tune("winosb=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
+        if (wino_tune("winocs=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
+        if (wino_tune("winocs=") == 2) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
         switch (wino_tune("winoring=")) {
         case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
         case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
