@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ x, float* 
         if (MODE == 0) {
 #pragma unroll
             for (int cp = 0; cp < C / 2; ++cp) { const float v = xi[(size_t)(2 * cp + half) * hw + off]; s += ok ? v : 0.f; }
+        } else if (MODE == 2) {
         } else {
             // two [H][W][16] tensors; lane half h takes channels 8h..8h+7 of each (2 x float4 per tensor)
 #pragma unroll
@@ -41,6 +42,17 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ x, float* 
                 const float4 a = p4[0], b = p4[1];
                 s += ok ? (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) : 0.f;
             }
+        }
+    }
+    if (MODE == 2) {
+        // planar, but as aligned float4 row segments: element e = (channel, patch row, 4-pixel group), groups tx0-4 .. tx0+TW+3 (18 per row)
+        constexpr int G = (TW + 8) / 4, NE = C * PH * G;
+        for (int e = threadIdx.x; e < NE; e += 256) {
+            const int g = e % G, r = (e / G) % PH, c = e / (G * PH);
+            const int gy = ty0 + r - 1, gx = tx0 - 4 + 4 * g;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+            const float4 v = *reinterpret_cast<const float4*>(xi + (size_t)c * hw + (ok ? (size_t)gy * W + gx : 0));
+            s += ok ? v.x + v.y + v.z + v.w : 0.f;
         }
     }
     if (s == 123.456f) out[0] = s;
@@ -52,15 +64,16 @@ int main()
     float* x; float* out;
     hipMalloc(&x, n * 4); hipMemset(x, 0, n * 4); hipMalloc(&out, 64);
     const int grid = (W / TW) * (H / TH) * ninst;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, x, out, ninst);
+            else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, x, out, ninst);
             else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, x, out, ninst);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("%s: %.3f ms for %.2f GB of tensor (%.2f TB/s algorithmic; patch bytes incl. halo %.2f GB)\n", mode ? "channel-last [H][W][16] x2, 2 x float4 per lane" : "planar [C][H][W], 16 dword loads per lane  ",
+            printf("%s: %.3f ms for %.2f GB of tensor (%.2f TB/s algorithmic; patch bytes incl. halo %.2f GB)\n", mode == 2 ? "planar [C][H][W], aligned float4 row segments    " : mode ? "channel-last [H][W][16] x2, 2 x float4 per lane" : "planar [C][H][W], 16 dword loads per lane  ",
                    ms, n * 4 / 1e9, n * 4 / 1e9 / ms, (double)grid * 660 * C * 4 / 1e9);
         }
     }

@@ -833,7 +833,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
 {
     if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 3)) return 1;
     const int MB = p.Cout / 16;
-    if (p.Cout % 32 == 0 && p.H >= 4 && p.W >= 32 && wino32_on()) {
+    if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 32 && wino32_on()) {      // (Cin >= 32: at least 8 K steps, the continuous stream looks D + 1 = 3 steps ahead)
         const long units = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
         int tpw = wino_tpw(wgs, units);
         const dim3 grid((unsigned)(wgs / tpw));
