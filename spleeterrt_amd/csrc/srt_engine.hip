@@ -455,7 +455,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.Cin = L.cin; p.Cout = L.cout; p.H = T >> (6 - i); p.W = F >> (6 - i); p.ntiles = ntiles; p.nstems = ns;
             const int sk = 5 - i;                                               // skip tensor = raw[5-i]; up1 consumes conv6 alone
             p.srcA = eoff(e, e->raw[sk], (size_t)s0 * ntiles * e->raw_tile[sk]); p.srcA_stem = (size_t)ntiles * e->raw_tile[sk]; p.srcA_tile = e->raw_tile[sk];
-            if (i == 0) { p.CA = L.cin; p.srcB = p.srcA; }
+            if (i == 0) { p.CA = L.cin; p.srcB = p.srcA; p.srcB_stem = p.srcA_stem; p.srcB_tile = p.srcA_tile; }
             else {
                 p.CA = L.cin / 2;
                 p.srcB = eoff(e, e->up[i - 1], (size_t)s0 * ntiles * e->up_tile[i - 1]); p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];

@@ -473,16 +473,17 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 // CS 1: the units of a workgroup form ONE stream of K steps: the last D steps of a unit already fetch the first slabs / patches of the next
 // unit (instead of refetching the last ones as filler), and the next unit's first transformed patch comes out of the ordinary refills of the
 // last step, so a unit boundary is an epilogue and nothing else: no drained DMA queue, no extra barrier, no separate first transform.
-template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0>
+// NI: instances per workgroup (BA * BB * NI == 32 blocks): 1 for inputs of at least 4 x 32 pixels, 2 for 4 x 16 (up1: one instance is 16 blocks).
+template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0, int NI = 1>
 __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS && !(CS && EA), "rings (5 x 30 KiB = 150 KiB of LDS)");
-    static_assert(BA * BB == 32 && BB % 16 == 0 || BA * BB == 32, "tile");
+    static_assert(BA * BB * NI == 32 && (BA * BB) % 16 == 0, "tile");
     constexpr int UB1 = 4 * 16 * WINO_LD;                                    // one M block: 3328 floats = 13 pieces
     constexpr int UBUF = 2 * UB1, NUP = 26;                                  // two M blocks (consecutive in the packed layout)
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;
-    constexpr int PCH = PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
+    constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
     constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;                // DMA pieces per K step, per wave (the tail repeats the last piece)
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
     float* s_u = s_all;
@@ -497,7 +498,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const int cls = (simd >> 1) == 0 ? (hi ? 3 : 0) : (hi ? 2 : 1);
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int MB2 = p.Cout / 32, MB = p.Cout / 16;
-    const int nsp = tilesX * tilesY, upw = nsp * p.ntiles / tpw;             // workgroups per (stem, M-block pair)
+    const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;      // workgroups per (stem, M-block pair)
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
     const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
     const int m0 = mblk2 * 32;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const size_t hw = (size_t)p.H * p.W;
     const float* up = U + stem * u_stem + (size_t)(2 * mblk2) * UB1;         // K step k at + k * MB * UB1
 
-    const int blk = g * 16 + l15, ba = blk / BB, bb = blk % BB;
+    const int blk = g * 16 + l15, il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
 
     // ---- DMA pieces of a K step: 0..25 the U slab, 26.. the patch.  Wave w moves pieces w, w + 8, ... (DPW of them; past the end: the last one
@@ -523,14 +524,14 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const int lpiece = min(wave + 8 * (DPW - 1), NPIECE - 1);                // the last ("flex") piece
     const unsigned fm0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(last_patch ? UR * UBUF * 4 + (lpiece - NUP) * 1024 : lpiece * 1024));
     constexpr unsigned OOR = 0x80000000u;
-    const unsigned nrec = last_patch ? (unsigned)min((size_t)0x7fffffff, (size_t)4 * p.srcA_tile) : 0x7fffffffu;
+    const unsigned nrec = last_patch ? (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile) : 0x7fffffffu;
     // per-unit DMA state of the flex piece: descriptor base halves (wave-uniform) and the lane's offset.  For waves 0-1 (U piece) the base is the
     // U slab and the offset the lane's place in it, whatever the unit.  (64-bit selects on a uniform condition come out of the compiler as
     // vector selects, which an "s" asm operand cannot take: the halves are selected and pinned to SGPRs.)
     unsigned c_alo, c_ahi, c_blo, c_bhi, c_voff, n_alo, n_ahi, n_blo, n_bhi, n_voff;       // current / next unit
     struct UnitBase { unsigned alo, ahi, blo, bhi; };                        // (uniform members only: with the per-lane offset in the same struct the compiler treats all of it as divergent)
     auto unit_base = [&](int unit) {
-        const int tile0 = unit / nsp;
+        const int tile0 = (unit / nsp) * NI;
         const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile0 * p.srcB_tile), bu_ = (size_t)up;
         UnitBase u;
         u.alo = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)ba_ : (unsigned)bu_); u.ahi = __builtin_amdgcn_readfirstlane(last_patch ? (unsigned)(ba_ >> 32) : (unsigned)(bu_ >> 32));
@@ -538,12 +539,12 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         return u;
     };
     auto unit_voff = [&](int unit) {
-        const int sp = unit % nsp, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
         const int e = (lpiece - NUP) * 64 + lane;
-        const int j = e % PR4, row = (e / PR4) % PH, c = e / (PR4 * PH);
+        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
-        const bool ok = e >= 0 && e < NF4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
-        const unsigned pvoff = ok ? 4u * (unsigned)((size_t)c * hw + (size_t)gy * p.W + gx) : OOR;
+        const bool ok = e >= 0 && e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const unsigned pvoff = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;   // srcA_tile == srcB_tile (launcher)
         return last_patch ? pvoff : (unsigned)(lpiece * 1024 + lane * 16);
     };
     auto unit_cur = [&](int unit) { const UnitBase u = unit_base(unit); c_alo = u.alo; c_ahi = u.ahi; c_blo = u.blo; c_bhi = u.bhi; c_voff = unit_voff(unit); };
@@ -573,16 +574,16 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         if (i == DPW - 1) dma_flex(ku, ubuf, kp, pslot);
         else dma_u(i, ku, ubuf);
     };
-    const int poff = (kq * PH + 2 * ba) * PROW + 2 * bb + 3;                 // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
+    const int poff = ((kq * NI + il) * PH + 2 * ba) * PROW + 2 * bb + 3;     // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
     const int aoff = (kq * 16 + l15) * WINO_LD;
     const int nk = p.Cin / 4;
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
     float* obase; bool blk_ok;
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = unit / nsp, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
-        blk_ok = a0 < p.H && b0 < p.W;
-        obase = p.outAct + stem * p.out_stem + tile * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
+        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
+        blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
+        obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
     };
 
     auto body = [&](auto cc) __attribute__((always_inline)) {
@@ -775,7 +776,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 // Which decoder layers (bit i = up(i+1)) run this form.  The default is the set measured faster than the direct kernels on
 // MI355X at 64 tiles x 4 stems; a -DSRT_TUNING build overrides it with SRT_TUNE=wino=<mask>.
 #ifndef SRT_WINO_DEFAULT_MASK
-#define SRT_WINO_DEFAULT_MASK 30      // up2..up5 (up1: 0.80 vs 0.79 ms for the direct kernel at 64 tiles x 4 stems)
+#define SRT_WINO_DEFAULT_MASK 31      // up1..up5 (round 2 kept up1 direct: 0.80 vs 0.79 ms with the 16-channel kernel; the 32-channel one is measured in DESIGN.md section 3.2b)
 #endif
 #ifdef SRT_TUNING
 static int wino_tune(const char* key)                                        // key includes the '='
@@ -833,6 +834,12 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
 {
     if (!U || p.in16 || p.out16 || p.srcA_tile != p.srcB_tile || (size_t)16 * p.srcA_tile > 0x7fffffffu || p.Cout % 16 || p.Cin % 4 || p.CA % 4 || (p.H & 1) || (p.W & 3)) return 1;
     const int MB = p.Cout / 16;
+    if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 16 && p.W < 32 && wino32_on()) {     // 4 x 16 .. 28 inputs (up1 of 256 x 1024 tiles): two instances per workgroup
+        const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
+        const int tpw = wino_tpw(wgs, units);
+        SRT_LAUNCH((srt_dec_wino32<2, 8, 0, 3, 2, 1, 1, 0, 1, 1, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 32 && wino32_on()) {      // (Cin >= 32: at least 8 K steps, the continuous stream looks D + 1 = 3 steps ahead)
         const long units = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
         int tpw = wino_tpw(wgs, units);
