@@ -97,6 +97,8 @@ struct srt_engine {
     float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     float* wino_u[6]; size_t wino_u_stem[6];           // Winograd-transformed decoder weights (srt_nn4.hip), layers in srt_wino_mask() only
+    float* wino_e[6]; size_t wino_e_stem[6];           // the same for the encoder layers that can run in Winograd form (down4..down6)
+    float* act32[6];                                   // fp32 act(BN(raw_i)) copies, i = 2..4: the inputs of those layers (written by their producers)
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
     size_t raw_tile[6], up_tile[6];                    // elements per instance
@@ -170,7 +172,7 @@ static void free_all(srt_engine* e)
     if (e->ws) hipFree(e->ws);
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
-    for (int i = 0; i < 6; ++i) if (e->wino_u[i]) hipFree(e->wino_u[i]);
+    for (int i = 0; i < 6; ++i) { if (e->wino_u[i]) hipFree(e->wino_u[i]); if (e->wino_e[i]) hipFree(e->wino_e[i]); if (e->act32[i]) hipFree(e->act32[i]); }
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
     for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act16buf[i]) hipFree(e->act16buf[i]); }
     void* misc[] = { e->preWin, e->postWin, e->twiddle, e->spec, e->spec2, e->mag, e->masks, e->frames };
@@ -193,6 +195,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail(-3, "srtCreate: no current HIP device"); }
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
+    memset(e->wino_e, 0, sizeof e->wino_e); memset(e->wino_e_stem, 0, sizeof e->wino_e_stem); memset(e->act32, 0, sizeof e->act32);
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -225,6 +228,12 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
         if (cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && ((srt_wino_mask() >> i) & 1) && U.cout % 16 == 0 && U.cin % 4 == 0) {
             e->wino_u_stem[i] = (size_t)U.cin * U.cout * 52;
             EALLOC(e->wino_u[i], S * e->wino_u_stem[i]);
+        }
+        const LayerOff& Dn = e->lo.down[i];
+        if (cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && i >= 1 && srt_enc_wino_covers(Dn.cin, Dn.cout, cfg->T >> i, cfg->F >> i)) {
+            e->wino_e_stem[i] = (size_t)Dn.cin * Dn.cout * 52;
+            EALLOC(e->wino_e[i], S * e->wino_e_stem[i]);
+            EALLOC(e->act32[i - 1], S * NT * ((size_t)ENC_CH[i - 1][1] * (HW >> (2 * i))));        // act(BN(raw_{i-1})): this layer's input
         }
     }
     // fp16 activation storage: every layer between down1 and up6 must run on the fp16-MFMA kernels, which stage aligned
@@ -284,6 +293,7 @@ static int pack_stem(srt_engine* e, int stem)
         if (e->wpack16_down[i] && srt_launch_pack16(c + D.w, e->wpack16_down[i] + stem * e->wpack16_down_stem[i], D.cin, D.cout, D.cp, 0, e->stream)) return fail(-2, "pack launch failed");
         if (e->wpack16_up[i] && srt_launch_pack16(c + U.w, e->wpack16_up[i] + stem * e->wpack16_up_stem[i], U.cin, U.cout, U.cp, 1, e->stream)) return fail(-2, "pack launch failed");
         if (e->wino_u[i] && srt_launch_pack_wino(c + U.w, e->wino_u[i] + stem * e->wino_u_stem[i], U.cin, U.cout, e->stream)) return fail(-2, "pack launch failed");
+        if (e->wino_e[i] && srt_launch_pack_wino_enc(c + D.w, e->wino_e[i] + stem * e->wino_e_stem[i], D.cin, D.cout, e->stream)) return fail(-2, "pack launch failed");
     }
     if (srt_launch_pack_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack2_u5 + (size_t)stem * 64 * 15 * 32, 64, 16, e->stream))
         return fail(-2, "pack launch failed");
@@ -401,6 +411,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
         const int actE = SRT_ACT_LEAKY, actD = SRT_ACT_RELU;
         const float* cbase = e->coeff_all + (size_t)s0 * SRT_COEFF_STRIDE;
         char nm[32];
+        bool act_ready = false;                                                 // act32[i-1] holds act(BN(raw_{i-1})) of this batch
         for (int i = 0; i < 6; ++i) {                                           // encoder (spleeter.c:182-238)
             const LayerOff& L = e->lo.down[i];
             SrtConvParams p; memset(&p, 0, sizeof p);
@@ -436,10 +447,33 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
                 if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
             }
+            // Winograd form (down4..down6 of launches above 16 instances): reads the act(BN(raw)) copy of its input, writes raw + its own copy when
+            // the next layer runs here too.  The first such layer's input copy comes from a batched bn+act pass over the direct producer's raw tensor.
+            const bool ewino = !few && e->wino_e[i] && !e->act16;
+            if (ewino) {
+                if (!act_ready) {
+                    const LayerOff& P = e->lo.down[i - 1];
+                    TimerScope ta(e, "actcopy");
+                    if (srt_launch_bn_act_batch(e->raw[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1], e->act32[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1],
+                                                cbase + P.bn + P.cout, cbase + P.bn, SRT_COEFF_STRIDE, ns, ntiles, P.cout, e->raw_tile[i - 1] / P.cout,
+                                                actE, elu_mask, e->cfg.variant, e->stream)) return fail(-2, "bn-act launch failed");
+                }
+                p.srcA = e->act32[i - 1] + (size_t)s0 * ntiles * e->raw_tile[i - 1]; p.srcB = p.srcA;
+                p.inScale = p.inShift = nullptr;
+                act_ready = i + 1 < 6 && e->wino_e[i + 1] != nullptr;       // this layer writes the next one's input copy
+                if (act_ready) {
+                    p.outAct = e->act32[i] + (size_t)s0 * ntiles * e->raw_tile[i];
+                    p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
+                }
+            } else act_ready = false;
             snprintf(nm, sizeof nm, "down%d", i + 1);
             TimerScope ts(e, nm);
             int rc2 = 1;
-            if (e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_down[i]) {
+            if (ewino) {
+                rc2 = srt_launch_enc_wino(p, e->wino_e[i] + (size_t)s0 * e->wino_e_stem[i], e->wino_e_stem[i], e->stream);
+                if (rc2 == 1) return fail(-4, "internal: Winograd encoder layer not covered by its launcher");
+            }
+            if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_down[i]) {
                 p.wpack16 = e->wpack16_down[i] + (size_t)s0 * e->wpack16_down_stem[i]; p.wpack16_stem = e->wpack16_down_stem[i];
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
                 rc2 = srt_launch_enc_f16(p, e->stream);

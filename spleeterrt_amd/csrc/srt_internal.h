@@ -103,6 +103,13 @@ void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s
 // when the layer is not covered.  srt_wino_mask(): bit i set = up(i+1) runs this form (large batches, fp32 MFMA path).
 int  srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s);
 int  srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s);
+// encoder layers in Winograd form (srt_nn4.hip, srt_enc_wino32): U from the OIHW weights; the layer reads act(BN(raw)) of its input (srcA) and
+// writes raw (outRaw) + optionally its own act(BN(.)) copy (outAct with bnScale / bnShift).  srt_enc_wino_covers: geometry test of the launcher.
+int  srt_launch_pack_wino_enc(const float* w, float* u, int Cin, int Cout, hipStream_t s);
+int  srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s);
+int  srt_enc_wino_covers(int Cin, int Cout, int H, int W);
+int  srt_launch_bn_act_batch(const float* raw, float* out, const float* scale, const float* shift, size_t coeff_stem, int nstems, int ntiles, int C, size_t hw,
+                             int act, unsigned elu_mask, int variant, hipStream_t s);
 int  srt_wino_mask();
 int  srt_wino_force();
 

@@ -116,6 +116,31 @@ int srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scal
     SRT_LAUNCH(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, raw16, out, scale, shift, C, hw, kind, variant);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// The same for a whole batch, [stem][tile][C][hw] -> [stem][tile][C][hw]: the act(BN(raw)) copy a Winograd-form encoder layer reads (srt_nn4.hip:
+// the non-linearity cannot ride through the input transform) when its producer was a direct kernel, which stores the raw tensor only.
+__global__ void __launch_bounds__(256) srt_bn_act_batch_kernel(const float* __restrict__ raw, float* __restrict__ out, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 size_t coeff_stem, int ntiles, int C, size_t hw4, int act, unsigned elu_mask, int variant)
+{
+    const int sc = blockIdx.y, stem = sc / C, c = sc % C;                    // one (stem, channel) per grid row: its BN constants are scalars
+    const SrtAct actp = srt_act_params(((elu_mask >> stem) & 1u) ? SRT_ACT_ELU : act, variant);
+    const float a = scale[stem * coeff_stem + c], b = shift[stem * coeff_stem + c];
+    const size_t per = (size_t)ntiles * hw4;                                 // float4s of this (stem, channel) over the tiles
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
+        const size_t tile = e / hw4, i = e % hw4;
+        const size_t off = (((size_t)stem * ntiles + tile) * C + c) * hw4 + i;
+        const float4 v = reinterpret_cast<const float4*>(raw)[off];
+        reinterpret_cast<float4*>(out)[off] = srt_enc_input4(v, a, b, actp);
+    }
+}
+int srt_launch_bn_act_batch(const float* raw, float* out, const float* scale, const float* shift, size_t coeff_stem, int nstems, int ntiles, int C, size_t hw,
+                            int act, unsigned elu_mask, int variant, hipStream_t s)
+{
+    if (hw % 4) return -1;
+    const size_t per = (size_t)ntiles * (hw / 4);
+    const unsigned bx = (unsigned)((per + 255) / 256 > 64 ? 64 : (per + 255) / 256);
+    SRT_LAUNCH(srt_bn_act_batch_kernel, dim3(bx, nstems * C), dim3(256), 0, s, raw, out, scale, shift, coeff_stem, ntiles, C, hw / 4, act, elu_mask, variant);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 __global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t n)
 {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = (float)src[e];

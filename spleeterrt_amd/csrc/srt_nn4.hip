@@ -39,23 +39,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------- weight transform
 // 1-D: p = 1 taps (k = 4, 2, 0) -> [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2];  p = 0 taps (k = 3, 1) -> [g0, g0+g1, g1]
+// ENC: the taps in ascending order (stride-2 convolution of the encoder: odd input plane k = 0, 2, 4, even plane k = 1, 3) instead of the
+// transposed convolution's descending one
+template <bool ENC = false>
 __device__ __forceinline__ int wino_w1d(int p, const float* g, int stride, float* o)      // returns the number of points
 {
     if (p) {
-        const float g0 = g[4 * stride], g1 = g[2 * stride], g2 = g[0];
+        const float g0 = g[(ENC ? 0 : 4) * stride], g1 = g[2 * stride], g2 = g[(ENC ? 4 : 0) * stride];
         o[0] = g0; o[1] = 0.5f * ((g0 + g2) + g1); o[2] = 0.5f * ((g0 + g2) - g1); o[3] = g2;
         return 4;
     }
-    const float g0 = g[3 * stride], g1 = g[stride];
+    const float g0 = g[(ENC ? 1 : 3) * stride], g1 = g[(ENC ? 3 : 1) * stride];
     o[0] = g0; o[1] = g0 + g1; o[2] = g1;
     return 3;
 }
+// ENC: w is the encoder's OIHW [Cout][Cin][5][5]; otherwise the decoder's [Cin][Cout][5][5].  Same packed layout either way.
+template <bool ENC>
 __global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cin * Cout) return;
     const int ci = idx / Cout, co = idx % Cout;
-    const float* g = w + ((size_t)ci * Cout + co) * 25;                      // [ky][kx]
+    const float* g = w + (ENC ? (size_t)co * Cin + ci : (size_t)ci * Cout + co) * 25;      // [ky][kx]
     float out[WINO_LD];
     int n = 0;
 #pragma unroll
@@ -64,7 +69,7 @@ __global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restr
         float rowt[5][4];                                                    // x transform of each kernel row ky
         int nx = 0;
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky) nx = wino_w1d(px, g + ky * 5, 1, rowt[ky]);
+        for (int ky = 0; ky < 5; ++ky) nx = wino_w1d<ENC>(px, g + ky * 5, 1, rowt[ky]);
         const int ny = py ? 4 : 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -72,7 +77,7 @@ __global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restr
             float col[5], t[4];
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) col[ky] = rowt[ky][j];
-            wino_w1d(py, col, 1, t);
+            wino_w1d<ENC>(py, col, 1, t);
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (i < ny) out[n + i * nx + j] = t[i];
         }
@@ -87,7 +92,13 @@ __global__ void srt_pack_wino_kernel(const float* __restrict__ w, float* __restr
 int srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s)
 {
     if (Cin % 4 || Cout % 16) return -1;
-    SRT_LAUNCH(srt_pack_wino_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
+    SRT_LAUNCH(srt_pack_wino_kernel<false>, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int srt_launch_pack_wino_enc(const float* w, float* u, int Cin, int Cout, hipStream_t s)
+{
+    if (Cin % 4 || Cout % 16) return -1;
+    SRT_LAUNCH(srt_pack_wino_kernel<true>, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -772,6 +783,296 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     else body(std::integral_constant<int, 3>{});
 }
 
+// ------------------------------------------------------------------------------------------- encoder layers in Winograd form
+// The stride-2 5x5 convolution of the encoder (spleeter.c:182-238; TF-SAME: pad 1 before, 2 after) seen from the input's four parity planes:
+// output row oy reads the ODD input rows 2(oy-1)+1, 2oy+1, 2(oy+1)+1 with taps ky = 0, 2, 4 and the EVEN rows 2oy, 2(oy+1) with taps ky = 1, 3.
+// Over blocks of 2 x 2 OUTPUT pixels that is F(2,3) on an odd plane and F(2,2) on an even one, per axis: the same 16 + 12 + 12 + 9 = 49
+// products per block and (ci, co) against 100, with the same B / G / A matrices as the decoder (tests/test_wino_algebra.py holds the algebra).
+// Differences from srt_dec_wino32, whose structure this kernel shares (class-split waves, two M blocks per wave, fenced bursts, staggered
+// pairs, units as one continuous K stream):
+//   * a block's 49 inputs are 49 DIFFERENT pixels (rows 4ya-1 .. 4ya+5, columns 4xb-1 .. 4xb+5; a class takes every second row / column of
+//     the patch), so the workgroup's patch is (4 BA + 3) x (4 BB + 8) pixels per channel: 13-14 DMA pieces per K step beside the 26 of the U slab;
+//   * the input must already be act(BN(raw)) - the non-linearity cannot ride through the transform - so the PRODUCER of the tensor supplies
+//     that copy (the engine keeps one for the inputs of the layers that run here) and this kernel writes its own when p.outAct is set;
+//   * the four classes ADD into the same 2 x 2 outputs, and they live in four different waves: at the end of a unit the waves exchange their
+//     classes' outputs through 32 KiB of LDS, one M block at a time, and each lane finishes one of its four channels (+ bias -> raw, and
+//     act(BN(.)) -> the copy for the next layer).
+template <int BA, int BB, int NI, int ABL = 0>
+__global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
+{
+    static_assert(BA * BB * NI == 32 && (BA * BB) % 16 == 0, "tile");
+    constexpr int UR = 3, D = 2;                                             // rings of three, slabs two K steps ahead, one barrier per K step
+    constexpr int UB1 = 4 * 16 * WINO_LD, UBUF = 2 * UB1, NUP = 26;
+    constexpr int TH = 2 * BA, TW = 2 * BB;                                  // OUTPUT pixels per instance
+    constexpr int PH = 4 * BA + 3, PROW = 4 * BB + 8, PR4 = PROW / 4;        // input patch
+    constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
+    constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;
+    static_assert(DPW == 5 && NPP >= 7 && NPP <= 14, "piece map: per wave three U pieces, one U-or-patch piece, one patch piece");
+    constexpr int XBUF = 4 * 2 * 16 * 16 * 4;                                // class exchange: [class][group][channel of the M block][block][2 x 2 outputs]
+    __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF + XBUF];
+    float* s_u = s_all;
+    float* s_p = s_all + UR * UBUF;
+    float* s_x = s_all + UR * UBUF + UR * PBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int simd = wave & 3, hi = wave >> 2, g = simd & 1;
+    const int cls = (simd >> 1) == 0 ? (hi ? 3 : 0) : (hi ? 2 : 1);
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
+    const int MB2 = p.Cout / 32, MB = p.Cout / 16;
+    const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;
+    const int pos = srt_xcd_order(upw * MB2 * p.nstems);
+    const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
+    const int m0 = mblk2 * 32;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const float* up = U + stem * u_stem + (size_t)(2 * mblk2) * UB1;
+
+    const int blk = g * 16 + l15, il = blk / (BA * BB), ba = (blk / BB) % BA, bb = blk % BB;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
+
+    // ---- DMA pieces of a K step: 0..25 the U slab, 26.. the patch.  Wave w: pieces w, w+8, w+16 (U), w+24 (U for waves 0-1, patch piece w-2
+    // otherwise: the "flex" piece, one buffer_load ... lds with scalar-selected operands), w+32 (patch piece w+6, the last one again past the end)
+    const bool flex_patch = wave >= 2;
+    unsigned dvoff[3], dm0[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dvoff[i] = (unsigned)((wave + 8 * i) * 1024 + lane * 16);
+        dm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wave + 8 * i) * 1024));
+    }
+    const int fpiece = wave + 24, ppiece = min(wave + 6, NPP - 1);           // flex: slab piece (waves 0-1) or patch piece fpiece - 26; pure patch piece
+    const unsigned fm0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(flex_patch ? UR * UBUF * 4 + (fpiece - NUP) * 1024 : fpiece * 1024));
+    const unsigned pm0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(UR * UBUF * 4 + ppiece * 1024));
+    constexpr unsigned OOR = 0x80000000u;
+    const unsigned prec = (unsigned)min((size_t)0x7fffffff, (size_t)4 * NI * p.srcA_tile), frec = flex_patch ? prec : 0x7fffffffu;
+    unsigned c_flo, c_fhi, c_plo, c_phi, c_fvoff, c_pvoff, n_flo, n_fhi, n_plo, n_phi, n_fvoff, n_pvoff;      // DMA state of the current / next unit
+    struct UnitBase { unsigned flo, fhi, plo, phi; };
+    auto unit_base = [&](int unit) {
+        const int tile0 = (unit / nsp) * NI;
+        const size_t bi_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bu_ = (size_t)up;
+        UnitBase u;
+        u.plo = __builtin_amdgcn_readfirstlane((unsigned)bi_); u.phi = __builtin_amdgcn_readfirstlane((unsigned)(bi_ >> 32));
+        u.flo = __builtin_amdgcn_readfirstlane(flex_patch ? (unsigned)bi_ : (unsigned)bu_); u.fhi = __builtin_amdgcn_readfirstlane(flex_patch ? (unsigned)(bi_ >> 32) : (unsigned)(bu_ >> 32));
+        return u;
+    };
+    // patch float4 e = ((c * NI + ii) * PH + row) * PR4 + j  <-  channel 4k+c, instance tile0+ii, input row 4 ty0 - 1 + row, columns 4 tx0 - 4 + 4j .. +3
+    auto patch_voff = [&](int unit, int piece) {
+        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * BB, ty0 = (sp / tilesX) * BA;     // tile origin in BLOCKS
+        const int e = piece * 64 + lane;
+        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+        const int gy = 4 * ty0 - 1 + row, gx = 4 * tx0 - 4 + 4 * j;
+        const bool ok = piece >= 0 && e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        return ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;
+    };
+    auto unit_cur = [&](int unit) {
+        const UnitBase u = unit_base(unit); c_flo = u.flo; c_fhi = u.fhi; c_plo = u.plo; c_phi = u.phi;
+        c_fvoff = flex_patch ? patch_voff(unit, fpiece - NUP) : (unsigned)(fpiece * 1024 + lane * 16); c_pvoff = patch_voff(unit, ppiece);
+    };
+    auto unit_nxt = [&](int unit) {
+        const UnitBase u = unit_base(unit); n_flo = u.flo; n_fhi = u.fhi; n_plo = u.plo; n_phi = u.phi;
+        n_fvoff = flex_patch ? patch_voff(unit, fpiece - NUP) : (unsigned)(fpiece * 1024 + lane * 16); n_pvoff = patch_voff(unit, ppiece);
+    };
+    auto unit_nxt_is_cur = [&]() { n_flo = c_flo; n_fhi = c_fhi; n_plo = c_plo; n_phi = c_phi; n_fvoff = c_fvoff; n_pvoff = c_pvoff; };
+    auto unit_advance = [&]() { c_flo = n_flo; c_fhi = n_fhi; c_plo = n_plo; c_phi = n_phi; c_fvoff = n_fvoff; c_pvoff = n_pvoff; };
+    const unsigned kstep_bytes = (unsigned)(16 * hw), ustep_bytes = (unsigned)((size_t)MB * UB1 * 4);
+    auto dma_u = [&](int i, int ku, int ubuf) {
+        const float* src = up + (size_t)ku * MB * UB1;
+        const unsigned dst = dm0[i] + (unsigned)ubuf * (unsigned)(UBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(dvoff[i]), "s"(src), "s"(dst) : "memory");
+    };
+    auto dma_flex = [&](int ku, int ubuf, int kp, int pslot) {
+        i32x4 rs;
+        rs.x = (int)c_flo; rs.y = (int)(c_fhi & 0xffffu); rs.z = (int)frec; rs.w = 0x00020000;
+        const unsigned soff = flex_patch ? (unsigned)kp * kstep_bytes : (unsigned)ku * ustep_bytes;
+        const unsigned dst = fm0 + (flex_patch ? (unsigned)pslot * (unsigned)(PBUF * 4) : (unsigned)ubuf * (unsigned)(UBUF * 4));
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(c_fvoff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+    };
+    auto dma_patch = [&](int kp, int pslot) {
+        i32x4 rs;
+        rs.x = (int)c_plo; rs.y = (int)(c_phi & 0xffffu); rs.z = (int)prec; rs.w = 0x00020000;
+        const unsigned soff = (unsigned)kp * kstep_bytes;
+        const unsigned dst = pm0 + (unsigned)pslot * (unsigned)(PBUF * 4);
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(c_pvoff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+    };
+    auto dma = [&](int i, int ku, int ubuf, int kp, int pslot) {             // piece i of this wave
+        if (i < 3) dma_u(i, ku, ubuf);
+        else if (i == 3) dma_flex(ku, ubuf, kp, pslot);
+        else dma_patch(kp, pslot);
+    };
+    const int poff = ((kq * NI + il) * PH + 4 * ba) * PROW + 4 * bb + 3;     // this lane's block: patch rows +0..6, columns +0..6 (input column 4xb-1 first)
+    const int aoff = (kq * 16 + l15) * WINO_LD;
+    const int nk = p.Cin / 4;
+    const size_t ohw = (size_t)Ho * Wo;
+    size_t obase; bool blk_ok;
+    auto set_out_unit = [&](int unit) {
+        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, oy0 = (sp / tilesX) * TH + 2 * ba, ox0 = (sp % tilesX) * TW + 2 * bb;
+        blk_ok = tile < p.ntiles && oy0 < Ho && ox0 < Wo;                    // (Ho, Wo even: a block is inside the image or outside it)
+        obase = stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? oy0 : 0) * Wo + (blk_ok ? ox0 : 0);
+    };
+
+    auto body = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int CLS = decltype(cc)::value;
+        constexpr int X0 = CLS == 0 ? WINO_C11 : CLS == 1 ? WINO_C10 : CLS == 2 ? WINO_C01 : WINO_C00;
+        constexpr bool Y3 = CLS < 2, X3 = !(CLS & 1);                        // odd input plane (3 taps, 4 points) along y / x
+        constexpr int NY = Y3 ? 4 : 3, NX = X3 ? 4 : 3, NP = NY * NX, NQ = (NP + 3) / 4, NROW = Y3 ? 4 : 3;
+        constexpr int RQ = CLS >= 2 ? 0 : 1;                                 // quad whose burst carries the row transforms (staggered pairs)
+        f32x4 acc[2][NP];
+        float t3[4][4], t2[4][3];
+        float xr[4][4];                                                      // patch row r of the class: its plane's 4 (3) pixels
+        auto read_row = [&](const float* pbuf, int r) {
+            const float* q = pbuf + poff + (Y3 ? 2 * r : 2 * r + 1) * PROW + (X3 ? 0 : 1);
+            xr[r][0] = q[0]; xr[r][1] = q[2]; xr[r][2] = q[4];
+            if constexpr (X3) xr[r][3] = q[6];
+        };
+        auto rows = [&](int r) {
+            if constexpr (X3) wino_in3(xr[r][0], xr[r][1], xr[r][2], xr[r][3], t3[r]);
+            else wino_in2(xr[r][0], xr[r][1], xr[r][2], t2[r]);
+        };
+        float v[NP];
+        auto issue_first = [&]() {
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int i = 0; i < DPW; ++i) dma(i, min(j, nk - 1), j, min(j, nk - 1), j);
+        };
+        float4 a0[2], a1[2];
+        auto kstep = [&](int k, int su, int sp1, int sd, int sd1) __attribute__((always_inline)) {
+            if (k + 1 + D == nk) unit_advance();                             // the DMA state moves to the next unit with the first patch that belongs to it
+            const int kd = k + D >= nk ? k + D - nk : k + D, kp = k + 1 + D >= nk ? k + 1 + D - nk : k + 1 + D;
+            const float* ub = s_u + su * UBUF + aoff + X0;
+            const float* pbuf = s_p + sp1 * PBUF;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) { a0[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1); a1[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1 + 4); }
+            if constexpr (RQ == 0 && ABL != 4) {
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) read_row(pbuf, r);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WinoFor<0, NQ>::run([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int nm = (4 * q + 4 <= NP) ? 4 : NP - 4 * q;
+                float4 a[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    a[mb] = a0[mb]; a0[mb] = a1[mb];
+                    if constexpr (q + 2 < NQ && ABL != 5) a1[mb] = *reinterpret_cast<const float4*>(ub + mb * UB1 + 4 * (q + 2));
+                }
+                if constexpr (ABL != 3) {
+#pragma unroll
+                    for (int i = 0; i < DPW; ++i) if (i * NQ / DPW == q) dma(i, kd, sd, kp, sd1);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], acc[mb][4 * q], 0, 0, 0);
+                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], acc[mb][4 * q + 1], 0, 0, 0);
+                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], acc[mb][4 * q + 2], 0, 0, 0);
+                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], acc[mb][4 * q + 3], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // the quad's vector work stays behind its eight MFMAs
+                if constexpr (ABL != 4) {
+                    if constexpr (q == 0) {
+                        constexpr int l0 = 4 * (NQ - 1);
+                        WinoFor<l0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+                        if constexpr (RQ == 0) {
+#pragma unroll
+                            for (int r = 0; r < NROW; ++r) rows(r);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NROW; ++r) read_row(pbuf, r);
+                        }
+                    } else {
+                        if constexpr (q == 1 && RQ == 1) {
+#pragma unroll
+                            for (int r = 0; r < NROW; ++r) rows(r);
+                        }
+                        WinoFor<4 * q - 4, 4 * q>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        unit_cur(unit0);
+        if (tpw > 1) unit_nxt(unit0 + 1); else unit_nxt_is_cur();
+        issue_first();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int x = 0; x < NP; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
+        WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
+        // patch D -> slot D: the wave's patch pieces only (its U pieces of this round went out above); from here on exactly DPW DMA instructions per step
+        if (flex_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
+        dma_patch(min(D, nk - 1), D % UR);
+        int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;
+        for (int t = 0; t < tpw; ++t) {
+        for (int k = 0; k < nk; ++k) {
+            // vmcnt: everything older than this wave's last step of pieces has landed (U slab k, patch k+1); the prologue's extra patch pieces are older still
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - 1) * DPW)); __syncthreads(); }
+            kstep(k, su, sp1, sd, sd1);
+            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
+        }
+        // ---- unit epilogue: the four classes' 2 x 2 outputs meet in LDS, one M block at a time; lane (kq, l15) of the class-c wave finishes channel
+        // 4 kq + c of the M block for its block: sum in the fixed order (C11 + C10) + (C01 + C00), + bias -> raw; act(BN(.)) -> the copy
+        set_out_unit(unit0 + t);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m[NP];
+#pragma unroll
+                for (int x = 0; x < NP; ++x) m[x] = acc[mb][x][r];
+                float y[2][2];
+                wino_out2d<NY, NX>(m, y);
+                *reinterpret_cast<float4*>(&s_x[((((CLS * 2 + g) * 16) + 4 * kq + r) * 16 + l15) * 4]) = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+            }
+            __syncthreads();
+            {
+                const int ch = 4 * kq + CLS;
+                float4 c4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) c4[c] = *reinterpret_cast<const float4*>(&s_x[((((c * 2 + g) * 16) + ch) * 16 + l15) * 4]);
+                const int co = m0 + 16 * mb + ch;
+                const float bias = p.bias[stem * p.coeff_stem + co];
+                float o[4];
+                o[0] = ((c4[0].x + c4[1].x) + (c4[2].x + c4[3].x)) + bias; o[1] = ((c4[0].y + c4[1].y) + (c4[2].y + c4[3].y)) + bias;
+                o[2] = ((c4[0].z + c4[1].z) + (c4[2].z + c4[3].z)) + bias; o[3] = ((c4[0].w + c4[1].w) + (c4[2].w + c4[3].w)) + bias;
+                if (blk_ok) {
+                    float* dst = p.outRaw + obase + (size_t)co * ohw;
+                    *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+                    *reinterpret_cast<float2*>(dst + Wo) = make_float2(o[2], o[3]);
+                    if (p.outAct) {
+                        const float sc = p.bnScale[stem * p.coeff_stem + co], sf = p.bnShift[stem * p.coeff_stem + co];
+                        float* da = p.outAct + obase + (size_t)co * ohw;
+                        *reinterpret_cast<float2*>(da) = make_float2(srt_enc_epilogue(o[0], sc, sf, actp), srt_enc_epilogue(o[1], sc, sf, actp));
+                        *reinterpret_cast<float2*>(da + Wo) = make_float2(srt_enc_epilogue(o[2], sc, sf, actp), srt_enc_epilogue(o[3], sc, sf, actp));
+                    }
+                }
+            }
+            __syncthreads();                                                 // the exchange buffer is free again
+        }
+        if (t + 1 < tpw) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int x = 0; x < NP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+            if (t + 2 < tpw) unit_nxt(unit0 + t + 2);
+        }
+        }                                                                    // units
+    };
+    if (cls == 0) body(std::integral_constant<int, 0>{});
+    else if (cls == 1) body(std::integral_constant<int, 1>{});
+    else if (cls == 2) body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 3>{});
+}
+
 // ------------------------------------------------------------------------------------------- launcher
 // Which decoder layers (bit i = up(i+1)) run this form.  The default is the set measured faster than the direct kernels on
 // MI355X at 64 tiles x 4 stems; a -DSRT_TUNING build overrides it with SRT_TUNE=wino=<mask>.
@@ -895,6 +1196,36 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 3) / 4), wgs = units * MB * p.nstems;
         const int tpw = wino_tpw(wgs, units);
         SRT_LAUNCH((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+    } else return 1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Encoder layers in Winograd form (srt_enc_wino32): the input must be the producer's act(BN(raw)) copy.  Returns 1 when the layer is not covered.
+// Which layers: down4..down6 (Cin >= 64: at least 16 K steps per unit; the short-K layers before them would be all epilogue).
+// SRT_TUNE=encwino=0 keeps the direct kernels, encwino=<min Cin> moves the threshold (tuning builds).
+int srt_enc_wino_covers(int Cin, int Cout, int H, int W)
+{
+    int min_cin = 64;
+#ifdef SRT_TUNING
+    const int v = wino_tune("encwino=");
+    if (v == 0) return 0;
+    if (v > 0) min_cin = v;
+#endif
+    if (Cout % 32 || Cin % 4 || Cin < min_cin || Cin < 32 || (H & 3) || (W & 3)) return 0;
+    return H / 2 >= 4 && W / 2 >= 16;
+}
+int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
+{
+    if (!U || p.in16 || p.out16 || p.inScale || (size_t)16 * p.srcA_tile > 0x7fffffffu || !srt_enc_wino_covers(p.Cin, p.Cout, p.H, p.W)) return 1;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    if (Ho >= 4 && Wo >= 32) {
+        const long units = (long)((Wo + 31) / 32) * ((Ho + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
+        const int tpw = wino_tpw(wgs, units);
+        SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+    } else if (Ho >= 4 && Wo >= 16) {
+        const long units = (long)((Wo + 15) / 16) * ((Ho + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
+        const int tpw = wino_tpw(wgs, units);
+        SRT_LAUNCH((srt_enc_wino32<2, 8, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
     } else return 1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -60,3 +60,62 @@ def test_transposed_conv_equals_winograd_classes():
         y, npts = winograd(x, w)
         assert npts == 49
         assert np.abs(y - direct(x, w)).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------- encoder (csrc/srt_nn5.hip)
+# The stride-2 5x5 TF-SAME convolution (spleeter.c:182-238 via conv2d, pad 1 before / 2 after) seen from the input's parity planes:
+# output oy reads the ODD rows 2(oy-1)+1, 2oy+1, 2(oy+1)+1 with taps ky = 0, 2, 4 and the EVEN rows 2oy, 2(oy+1) with taps ky = 1, 3.
+# Over blocks of 2x2 OUTPUT pixels that is F(2,3) on the odd plane and F(2,2) on the even plane per axis: 16 + 12 + 12 + 9 = 49 products,
+# and the four classes ADD into the same 2x2 outputs.  Same B / G / A matrices as the decoder; the taps are taken in ascending order.
+def enc_taps(p):                    # kernel indices of the class, in the order the G matrices expect
+    return [0, 2, 4] if p == 1 else [1, 3]
+
+
+def enc_direct(x, w):
+    cin, H, W = x.shape
+    cout = w.shape[0]
+    y = np.zeros((cout, H // 2, W // 2))
+    for oy in range(H // 2):
+        for ox in range(W // 2):
+            for ky in range(5):
+                for kx in range(5):
+                    Y, X = 2 * oy + ky - 1, 2 * ox + kx - 1
+                    if 0 <= Y < H and 0 <= X < W:
+                        y[:, oy, ox] += w[:, :, ky, kx] @ x[:, Y, X]
+    return y
+
+
+def enc_winograd(x, w):
+    cin, H, W = x.shape
+    cout = w.shape[0]
+    xp = np.zeros((cin, H + 8, W + 8))                      # input row r at xp row r + 1 (row -1 = the pad-before row)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    y = np.zeros((cout, H // 2, W // 2))
+    npts = 0
+    for py in (1, 0):                                       # plane parity along y: 1 = odd input rows (3 taps), 0 = even (2 taps)
+        for px in (1, 0):
+            g = np.stack([np.stack([w[:, :, ky, kx] for kx in enc_taps(px)], -1) for ky in enc_taps(py)], -2)     # [co][ci][ny][nx]
+            U = np.einsum('ik,ockl,jl->ocij', GT[py], g, GT[px])
+            npts += U.shape[2] * U.shape[3]
+            for ya in range(H // 4):                        # block = outputs 2ya..2ya+1
+                for xb in range(W // 4):
+                    # patch of the block: input rows 4ya-1 .. 4ya+5 (xp rows 4ya .. 4ya+6); the odd plane is every second row from the
+                    # first, the even plane every second row from the second
+                    r0, c0 = 4 * ya, 4 * xb
+                    rows = [r0 + 2 * i for i in range(4)] if py else [r0 + 1 + 2 * i for i in range(4)]
+                    cols = [c0 + 2 * j for j in range(4)] if px else [c0 + 1 + 2 * j for j in range(4)]
+                    d = xp[:, rows][:, :, cols]
+                    V = np.einsum('ik,ckl,jl->cij', BT[py], d, BT[px])
+                    Yb = np.einsum('ik,okl,jl->oij', AT[py], np.einsum('ocij,cij->oij', U, V), AT[px])
+                    y[:, 2 * ya:2 * ya + 2, 2 * xb:2 * xb + 2] += Yb
+    return y, npts
+
+
+def test_strided_conv_equals_winograd_over_parity_planes():
+    rng = np.random.default_rng(11)
+    for (cin, cout, H, W) in ((3, 2, 8, 12), (1, 1, 4, 4), (2, 3, 4, 8)):
+        x = rng.standard_normal((cin, H, W))
+        w = rng.standard_normal((cout, cin, 5, 5))
+        y, npts = enc_winograd(x, w)
+        assert npts == 49
+        assert np.abs(y - enc_direct(x, w)).max() < 1e-12
