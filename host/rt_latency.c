@@ -19,6 +19,7 @@
 #include <string.h>
 #include <time.h>
 #include "Spleeter4Stems.h"
+#include "spleeterrt_amd.h"      /* srtLastError(): why an instance came up muted, if it did */
 
 #define COEFF_BYTES 39290900u
 
@@ -34,6 +35,7 @@ typedef struct {
     void *coeff[4];
     double init_ms, *us;        /* per-call wall time */
     float peak;
+    char init_error[256];       /* srtLastError() of this thread right after Init ("" = the instance is live) */
     pthread_barrier_t *start;
 } Job;
 
@@ -47,6 +49,8 @@ static void *run(void *arg)
     double t0 = now_us();
     Spleeter4StemsInit(msr, j->F, j->T, j->coeff);
     j->init_ms = (now_us() - t0) * 1e-3;
+    snprintf(j->init_error, sizeof j->init_error, "%s", srtLastError());
+    for (char *c = j->init_error; *c; ++c) if (*c == '"' || *c == '\\' || *c < 32) *c = ' ';
     pthread_barrier_wait(j->start);
     double next = now_us();
     for (int h = 0; h < j->hops; ++h) {
@@ -108,7 +112,7 @@ int main(int argc, char **argv)
         double *ord = (double *)malloc(sizeof(double) * (size_t)hops), *join = (double *)malloc(sizeof(double) * (size_t)hops);
         int no = 0, nj = 0;
         for (int h = 0; h < hops; ++h) { if ((h + 1) % T == 0) join[nj++] = j->us[h]; else ord[no++] = j->us[h]; }    /* hop h+1 completes a batch */
-        fprintf(f, "%s{\"init_ms\": %.1f, \"output_peak\": %.6g, ", i ? ", " : "", j->init_ms, j->peak);
+        fprintf(f, "%s{\"init_ms\": %.1f, \"init_error\": \"%s\", \"output_peak\": %.6g, ", i ? ", " : "", j->init_ms, j->init_error, j->peak);
         stats(f, "ordinary_hops", ord, no); fprintf(f, ", "); stats(f, "join_hops", join, nj);
         fprintf(f, "}");
         free(ord); free(join);

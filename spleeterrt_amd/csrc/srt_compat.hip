@@ -56,6 +56,7 @@ void* allocateSpleeterStr(void) { return calloc(1, sizeof(struct _spleeter)); }
 void initSpleeter(struct _spleeter* nn, size_t width, size_t height, int stemMode, void* coeff)
 {
     if (!nn) return;
+    SrtSetupLock setup;                                       // (srt_internal.h: set-up paths are serialised process-wide)
     memset(nn, 0, sizeof *nn);
     // VST callers pass int arguments (VST/Source/spleeter.h:4): only the low 32 bits are defined for them
     const int F = (int)(width & 0xffffffffu), T = (int)(height & 0xffffffffu);
@@ -118,6 +119,7 @@ struct StftCtx { srt_engine* eng; hipStream_t stream; };
 void InitSTFT(OfflineSTFT* st, size_t targetCore)
 {
     if (!st) return;
+    SrtSetupLock setup;
     const double w0 = 6.283185307179586476925286766559 / FFTSIZE;
     const float postScale = (float)FFTSIZE * ((1.0f / 2.0f) / (3.0f / 8.0f));
     for (unsigned i = 0; i < FFTSIZE; ++i) {

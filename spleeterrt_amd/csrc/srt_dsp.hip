@@ -265,7 +265,7 @@ int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
     const int blocks = (p.rows_total + fpb - 1) / fpb;
     if (blocks <= 0) return 0;
     SRT_LAUNCH(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // Inverse STFT with the overlap-add fused in (no frame scratch, no second pass, no atomics).
@@ -384,7 +384,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
     SRT_LAUNCH(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------- residual chain / ratio mask
@@ -418,7 +418,7 @@ int srt_launch_residual(const SrtResidualParams& p, hipStream_t s)
 {
     if (p.rows <= 0) return 0;
     SRT_LAUNCH(srt_residual_kernel, dim3(p.rows, 2), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 __global__ void __launch_bounds__(256) srt_time_residual_kernel(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out)
@@ -434,7 +434,7 @@ int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const 
 {
     if (!nb) return 0;
     SRT_LAUNCH(srt_time_residual_kernel, dim3((unsigned)((nb + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // Overlap-add across the chunks of a long stream: consecutive chunks share 3072 output samples (three hops of the last
@@ -452,7 +452,7 @@ int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, flo
 {
     if (first && last) return 0;
     SRT_LAUNCH(srt_carry_kernel, dim3((SRT_FFT - SRT_HOP) / 256, nplanes), dim3(256), 0, s, out, plane_len, tail, carry, first, last);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // Cross-stem ratio mask (what official Spleeter applies and the reference deliberately leaves out, README.MD:82-85):
@@ -488,7 +488,7 @@ int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s)
 {
     if (!count || nstems < 1) return 0;
     SRT_LAUNCH(srt_ratio_mask_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, masks, nstems, count);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------- streaming hop
@@ -586,5 +586,5 @@ int srt_launch_stream_hop(const SrtStreamHop& p, hipStream_t s)
     SRT_LAUNCH(srt_stream_inverse_kernel, dim3(4), dim3(256), 0, s, p);     // reads the delayed row ...
     if (hipGetLastError() != hipSuccess) return -1;
     SRT_LAUNCH(srt_stream_forward_kernel, dim3(1), dim3(256), 0, s, p);     // ... before the current frame overwrites it
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }

@@ -16,11 +16,21 @@
 #include <string>
 #include <vector>
 #include <cxxabi.h>
+#include <mutex>
+
+static std::recursive_mutex g_setup_mutex;
+SrtSetupLock::SrtSetupLock() { g_setup_mutex.lock(); }
+SrtSetupLock::~SrtSetupLock() { g_setup_mutex.unlock(); }
 
 static thread_local char g_err[512] = "";
+static thread_local hipError_t g_hip_noted = hipSuccess;               // HIP error behind the last failed launch (srt_launch_status)
+void srt_note_hip_error(hipError_t e) { g_hip_noted = e; }
 int srt_set_error(int code, const char* fmt, const char* detail)      // shared with the drop-in layers (srt_compat.hip, srt_stream.hip)
 {
-    snprintf(g_err, sizeof g_err, fmt, detail);
+    const int n = snprintf(g_err, sizeof g_err, fmt, detail);
+    if (g_hip_noted != hipSuccess && n > 0 && (size_t)n < sizeof g_err - 8)
+        snprintf(g_err + n, sizeof g_err - n, " [HIP: %s]", hipGetErrorString(g_hip_noted));
+    g_hip_noted = hipSuccess;
     return code;
 }
 static int fail(int code, const char* fmt, const char* detail = "") { return srt_set_error(code, fmt, detail); }
@@ -183,6 +193,7 @@ static void free_all(srt_engine* e)
 int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
 {
     if (!cfg || !out) return fail(-1, "srtCreate: null argument");
+    SrtSetupLock setup;
     if (cfg->F < 64 || cfg->F > 2048 || cfg->F % 64 || cfg->T < 64 || cfg->T % 64)
         return fail(-1, "srtCreate: F and T must be multiples of 64 (F <= 2048)");     // spleeter.c:113-119 floor-divides by 64
     if (cfg->n_stems < 1 || cfg->n_stems > SRT_MAX_STEMS || cfg->max_tiles < 1) return fail(-1, "srtCreate: bad n_stems / max_tiles");
@@ -304,6 +315,7 @@ static int pack_stem(srt_engine* e, int stem)
 int srtSetCoeffHost(srt_engine* e, int stem, const void* h)
 {
     if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffHost: bad argument");
+    SrtSetupLock setup;
     DeviceScope ds(e->device);
     HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, h, srtCoeffBytes(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -312,6 +324,7 @@ int srtSetCoeffHost(srt_engine* e, int stem, const void* h)
 int srtSetCoeffDevice(srt_engine* e, int stem, const void* d)
 {
     if (!e || !d || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffDevice: bad argument");
+    SrtSetupLock setup;
     DeviceScope ds(e->device);
     HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, d, srtCoeffBytes(), hipMemcpyDeviceToDevice, e->stream));
     return pack_stem(e, stem);
@@ -319,6 +332,7 @@ int srtSetCoeffDevice(srt_engine* e, int stem, const void* d)
 int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 {
     if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffFp16Host: bad argument");
+    SrtSetupLock setup;
     DeviceScope ds(e->device);
     uint16_t* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)SRT_COEFF_FLOATS * 2));
@@ -363,10 +377,13 @@ static int run_graphed(srt_engine* e, const GraphKey& key, bool valid, F&& issue
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipError_t er = hipStreamEndCapture(e->stream, &graph);
-    if (rc) {                                                              // the sequence itself failed (its error text is set): nothing to replay, graph mode stays on
+    if (rc) {
+        // A launch failed INSIDE the capture.  The arguments were validated above, so the likeliest cause is the capture itself having been
+        // invalidated from outside (another host thread's legacy-stream operation while this stream was capturing): run the sequence once
+        // more, eagerly - if it fails again the error is real and is returned; graph mode stays on either way.
         if (graph) hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc;
+        return issue();
     }
     if (er == hipSuccess && graph) er = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (er != hipSuccess || !exec) {                                       // capture is not available here: plain launches from now on
@@ -553,6 +570,7 @@ int srtForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
 int srtPrepareForward(srt_engine* e, const float* d_mag, int ntiles, float* d_masks)
 {
     if (!e) return fail(-1, "srtPrepareForward: null argument");
+    SrtSetupLock setup;
     DeviceScope ds(e->device);
     const int rc = srtForward(e, d_mag, ntiles, d_masks);     // allocates the workspace, captures + instantiates (graph mode), runs once
     if (rc) return rc;

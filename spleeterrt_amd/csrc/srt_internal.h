@@ -17,6 +17,13 @@
 // error text behind srtLastError() (thread-local), settable from every translation unit of the library; returns `code`
 int srt_set_error(int code, const char* fmt, const char* detail);
 
+// Set-up paths (engine creation, weight upload, graph pre-warm, the drop-in Init functions) are serialised process-wide: they use the legacy
+// null stream (synchronous copies, memsets, hipMemcpyToSymbol) and stream capture, and HIP refuses a null-stream operation issued by one host
+// thread while another thread's stream is capturing ("operation would make the legacy stream depend on a capturing blocking stream") - two
+// plugin instances initialised from two threads at once otherwise come up muted now and then.  Steady-state calls never take this lock: they
+// use explicit streams only and replay graphs that already exist.
+struct SrtSetupLock { SrtSetupLock(); ~SrtSetupLock(); };
+
 enum { SRT_ACT_LEAKY = 0, SRT_ACT_RELU = 1, SRT_ACT_ELU = 2 };
 
 // Every kernel launch of the library goes through SRT_LAUNCH: besides launching, it notes WHICH kernel (host stub pointer + the
@@ -25,6 +32,9 @@ enum { SRT_ACT_LEAKY = 0, SRT_ACT_RELU = 1, SRT_ACT_ELU = 2 };
 // size and geometry), not a table kept by hand.
 void srt_kernel_note(const void* fn, const char* text);
 void srt_kernel_note_reset();
+// status of the launch just issued on this thread: 0, or -1 with the HIP error kept for the message srt_set_error builds next
+void srt_note_hip_error(hipError_t e);
+static inline int srt_launch_status() { const hipError_t e = hipGetLastError(); if (e != hipSuccess) srt_note_hip_error(e); return e == hipSuccess ? 0 : -1; }
 #define SRT_LAUNCH(kernel, ...) do { srt_kernel_note((const void*)(kernel), #kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
 
 // One convolution layer evaluated for nstems x ntiles independent instances.

@@ -114,7 +114,7 @@ __global__ void srt_bn_act_kernel(const float* __restrict__ raw, int raw16, floa
 int srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s)
 {
     SRT_LAUNCH(srt_bn_act_kernel, dim3(1024), dim3(256), 0, s, raw, raw16, out, scale, shift, C, hw, kind, variant);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 // The same for a whole batch, [stem][tile][C][hw] -> [stem][tile][C][hw]: the act(BN(raw)) copy a Winograd-form encoder layer reads (srt_nn4.hip:
 // the non-linearity cannot ride through the input transform) when its producer was a direct kernel, which stores the raw tensor only.
@@ -139,7 +139,7 @@ int srt_launch_bn_act_batch(const float* raw, float* out, const float* scale, co
     const size_t per = (size_t)ntiles * (hw / 4);
     const unsigned bx = (unsigned)((per + 255) / 256 > 64 ? 64 : (per + 255) / 256);
     SRT_LAUNCH(srt_bn_act_batch_kernel, dim3(bx, nstems * C), dim3(256), 0, s, raw, out, scale, shift, coeff_stem, ntiles, C, hw / 4, act, elu_mask, variant);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 __global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t n)
 {
@@ -148,7 +148,7 @@ __global__ void srt_half_to_float_kernel(const _Float16* __restrict__ src, float
 int srt_launch_half_to_float(const void* src, float* dst, size_t n, hipStream_t s)
 {
     SRT_LAUNCH(srt_half_to_float_kernel, dim3(1024), dim3(256), 0, s, (const _Float16*)src, dst, n);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // up7 head: direct 16-tap stencil, both output channels per thread (bandwidth kernel; 1 MiB in, 2 MiB out per instance)
@@ -265,12 +265,12 @@ __global__ void srt_pack_kernel(const float* __restrict__ w, float* __restrict__
 int srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
 {
     SRT_LAUNCH(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 0);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 int srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s)
 {
     SRT_LAUNCH(srt_pack_kernel, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, CP, 1);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // fp16 container -> fp32, half-denormals flushed to zero, no Inf/NaN special case (main.c:423-434)
@@ -722,7 +722,7 @@ static int launch_enc_cfg(const SrtConvParams& p, hipStream_t s)
     const int Ho = p.H / 2, Wo = p.W / 2;
     dim3 grid(((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
     SRT_LAUNCH((srt_enc_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 static int launch_dec_cfg(const SrtConvParams& p, hipStream_t s)
@@ -730,7 +730,7 @@ static int launch_dec_cfg(const SrtConvParams& p, hipStream_t s)
     constexpr int SH = 32 / SW, TW = NSX * SW, TH = NSY * SH;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), (p.Cout + BM - 1) / BM, p.nstems * ((p.ntiles + NI - 1) / NI));
     SRT_LAUNCH((srt_dec_mfma<BM, WM, SW, NSX, NSY, NI, KC>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 static int launch_naive(void (*k)(const SrtConvParams), const SrtConvParams& p, size_t total, hipStream_t s)
@@ -738,7 +738,7 @@ static int launch_naive(void (*k)(const SrtConvParams), const SrtConvParams& p, 
     size_t bx = (total + 255) / 256;
     if (bx > 65535) bx = 65535;
     SRT_LAUNCH(k, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
@@ -780,7 +780,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 0 && p.in16) SRT_LAUNCH((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
         else if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
     if (p.Cout < 16) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
     if (p.Cout <= 32) return launch_dec_cfg<32, 1, 32, 2, 4, 1, 4>(p, s);                    // up4/up5: 4 rows x 64 cols
@@ -799,10 +799,10 @@ int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
         const unsigned grid = (unsigned)bx4 * p.nstems * p.ntiles;
         if (p.variant == 0) SRT_LAUNCH(srt_head_kernel4<true>, dim3(grid), dim3(256), 0, s, p);
         else SRT_LAUNCH(srt_head_kernel4<false>, dim3(grid), dim3(256), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
     size_t total = (size_t)p.H * p.W, bx = (total + 255) / 256;
     if (bx > 65535) bx = 65535;
     SRT_LAUNCH(srt_head_kernel, dim3((unsigned)bx, p.nstems * p.ntiles), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }

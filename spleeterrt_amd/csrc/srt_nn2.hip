@@ -24,7 +24,7 @@ __global__ void srt_pack_stemstack_kernel(const float* __restrict__ w0, size_t c
 int srt_launch_pack_stemstack(const float* w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s)
 {
     SRT_LAUNCH(srt_pack_stemstack_kernel, dim3(16), dim3(256), 0, s, w0, coeff_stem, nstems, wp2, Cin, Cout, CP2);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 // up5: wp2[(ci*15 + ky*3 + (dx+1))*32 + px*16 + co] = w[ci][co][ky][kx],  kx = px + 1 - 2*dx  (zero when kx is outside 0..4)
 __global__ void srt_pack_classstack_kernel(const float* __restrict__ w, float* __restrict__ wp2, int Cin, int Cout)
@@ -40,7 +40,7 @@ __global__ void srt_pack_classstack_kernel(const float* __restrict__ w, float* _
 int srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, hipStream_t s)
 {
     SRT_LAUNCH(srt_pack_classstack_kernel, dim3(64), dim3(256), 0, s, w, wp2, Cin, Cout);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------- LDS-DMA helper
@@ -794,7 +794,7 @@ static int launch_enc2_splitk(const SrtConvParams& p0, int ks, hipStream_t s)   
     if (hipGetLastError() != hipSuccess) return -1;
     const size_t total = p.ws_slice;
     SRT_LAUNCH(srt_splitk_reduce<false>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, p, (size_t)Ho * Wo, total);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int BM, int WM, int SW, int NSX, int NSY, int KC>
 static int launch_dec2_splitk(const SrtConvParams& p0, int ks, hipStream_t s)
@@ -807,7 +807,7 @@ static int launch_dec2_splitk(const SrtConvParams& p0, int ks, hipStream_t s)
     if (hipGetLastError() != hipSuccess) return -1;
     const size_t total = p.ws_slice;
     SRT_LAUNCH(srt_splitk_reduce<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, p, (size_t)4 * p.H * p.W, total);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 // base workgroup count of a plain launch with NI = 1 (what split-K multiplies)
 static long srt_base_wgs(const SrtConvParams& p, int H, int W, int TH, int TW, int BM)
@@ -838,7 +838,7 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
 #ifdef SRT_TUNING
     if constexpr (!STK) if (p.inScale) {                  // where the input BN + activation runs: encx = 15 (see srt_enc_mfma2)
         switch (tune("encx")) {
-        case 15: SRT_LAUNCH((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 15>), grid, dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 15: SRT_LAUNCH((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 15>), grid, dim3(256), 0, s, p); return srt_launch_status();
         }
     }
 #endif
@@ -846,11 +846,11 @@ static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
     constexpr int PWH_ = Enc2Pad<TW, SW>::value, LDSF_ = KC * NI * (2 * TH + 3) * 2 * PWH_ + 2 * ((KC * 25 * BM + 255) / 256 * 256) + BM + 2 * SRT_ENC_MAX_CIN;
     if constexpr (!STK && LDSF_ * 8 <= 160 * 1024) if (srt_use_dual() && grid.x % 2 == 0 && grid.x >= 1024) {   // two-tile workgroups (see srt_enc_mfma2, DUAL)
         SRT_LAUNCH((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 0, false, true>), dim3(grid.x / 2), dim3(512), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
 #endif
     SRT_LAUNCH((srt_enc_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
@@ -860,17 +860,17 @@ static int launch_dec2_cfg(const SrtConvParams& p, hipStream_t s)
 #ifdef SRT_TUNING
     if constexpr (!STK) if (tune("decx") == 20) {
         SRT_LAUNCH((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 20>), grid, dim3(256), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
 #endif
 #ifdef SRT_TUNING
     if constexpr (!STK) if (srt_use_dual() && grid.x % 2 == 0 && grid.x >= 1024) {
         SRT_LAUNCH((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK, 0, false, true>), dim3(grid.x / 2), dim3(512), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
 #endif
     SRT_LAUNCH((srt_dec_mfma2<BM, WM, SW, NSX, NSY, NI, KC, STK>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // Per-layer tile shapes.  Template arguments: <BM, WM, SW, NSX, NSY, NI, KC, stacked-M>.  The defaults below are the
@@ -892,20 +892,20 @@ static int launch_enc2_ablation(const SrtConvParams& p, hipStream_t s)          
 {
     dim3 grid(((p.W / 2 + 63) / 64) * ((p.H / 2 + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
     SRT_LAUNCH((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 4, false, ABL>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int ABL>
 static int launch_dec2_ablation(const SrtConvParams& p, hipStream_t s)
 {
     dim3 grid(((p.W + 31) / 32) * ((p.H + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
     SRT_LAUNCH((srt_dec_mfma2<64, 2, 32, 1, 4, 1, 4, false, ABL>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int NSX, int NSY>
 static int launch_dec16(const SrtConvParams& p, hipStream_t s)
 {
     SRT_LAUNCH((srt_dec16_kernel<NSX, NSY, 4>), dim3(((p.W + 16 * NSX - 1) / (16 * NSX)) * ((p.H + NSY - 1) / NSY) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 #endif
 
@@ -980,7 +980,7 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     if (tune("occ3") && p.Cout >= 64 && Wo >= 64) {                                      // three workgroups per CU on two-channel chunks
         dim3 grid(((Wo + 63) / 64) * ((p.H / 2 + 3) / 4) * ((p.Cout + 63) / 64) * p.nstems * p.ntiles);
         SRT_LAUNCH((srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, false, 30>), grid, dim3(256), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
 #endif
     if (Wo >= 64) {                                                                      // down3 / down4 class
@@ -1010,8 +1010,8 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
         case 11: return launch_dec16<8, 4>(p, s);
         case 12: return launch_dec16<2, 16>(p, s);
         case 14: return launch_dec16<8, 2>(p, s);
-        case 15: SRT_LAUNCH((srt_dec16_kernel<4, 4, 8>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 16: SRT_LAUNCH((srt_dec16_kernel<4, 4, 16>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 15: SRT_LAUNCH((srt_dec16_kernel<4, 4, 8>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return srt_launch_status();
+        case 16: SRT_LAUNCH((srt_dec16_kernel<4, 4, 16>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p); return srt_launch_status();
         case 1: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 1, 8, 1, 4, true>(p, s) : 1;   // class-stacked 32x32x2 forms (83 % row efficiency)
         case 2: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 4, 2, 1, 4, true>(p, s) : 1;
         case 3: return p.wpack2 ? launch_dec2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s) : 1;
@@ -1022,7 +1022,7 @@ int srt_launch_dec2(const SrtConvParams& p, hipStream_t s)
         }
 #endif
         SRT_LAUNCH((srt_dec16_kernel<4, 4, 4>), dim3(((p.W + 63) / 64) * ((p.H + 3) / 4) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
     {                                                                                    // small batches: split-K (see srt_launch_enc2)
         const size_t outf = (size_t)p.nstems * p.out_stem;

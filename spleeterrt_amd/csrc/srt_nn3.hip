@@ -35,7 +35,7 @@ __global__ void srt_pack16_kernel(const float* __restrict__ w, _Float16* __restr
 int srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s)
 {
     SRT_LAUNCH(srt_pack16_kernel, dim3(1024), dim3(256), 0, s, w, (_Float16*)wp16, Cin, Cout, CP, dec);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 __device__ __forceinline__ void srt_dma16h(const _Float16* gsrc, _Float16* lds_wave_base)
@@ -454,7 +454,7 @@ static int launch_dec16(const SrtConvParams& p, hipStream_t s)
     if (p.nsplit == 2) SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
     else if (p.in16) SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
     else SRT_LAUNCH((srt_dec_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 template <int SW, int NSX, int NSY, int NI>
 static int launch_enc16(const SrtConvParams& p, hipStream_t s)
@@ -465,7 +465,7 @@ static int launch_enc16(const SrtConvParams& p, hipStream_t s)
     if (p.nsplit == 2) SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 2>), grid, dim3(256), 0, s, p);
     else if (p.in16) SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 1, true>), grid, dim3(256), 0, s, p);
     else SRT_LAUNCH((srt_enc_f16<SW, NSX, NSY, NI, 1>), grid, dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)

@@ -93,13 +93,13 @@ int srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_
 {
     if (Cin % 4 || Cout % 16) return -1;
     SRT_LAUNCH(srt_pack_wino_kernel<false>, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 int srt_launch_pack_wino_enc(const float* w, float* u, int Cin, int Cout, hipStream_t s)
 {
     if (Cin % 4 || Cout % 16) return -1;
     SRT_LAUNCH(srt_pack_wino_kernel<true>, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, u, Cin, Cout);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------- transforms (registers)
@@ -1139,7 +1139,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
         SRT_LAUNCH((srt_dec_wino32<2, 8, 0, 3, 2, 1, 1, 0, 1, 1, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
     if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 32 && wino32_on()) {      // (Cin >= 32: at least 8 K steps, the continuous stream looks D + 1 = 3 steps ahead)
         const long units = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
@@ -1168,7 +1168,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
 #undef W32
 #endif
         SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return srt_launch_status();
     }
     if (p.H >= 8 && p.W >= 32) {
         const long units = (long)((p.W + 31) / 32) * ((p.H + 7) / 8) * p.ntiles, wgs = units * MB * p.nstems;
@@ -1197,7 +1197,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const int tpw = wino_tpw(wgs, units);
         SRT_LAUNCH((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
     } else return 1;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }
 
 // Encoder layers in Winograd form (srt_enc_wino32): the input must be the producer's act(BN(raw)) copy.  Returns 1 when the layer is not covered.
@@ -1227,5 +1227,5 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const int tpw = wino_tpw(wgs, units);
         SRT_LAUNCH((srt_enc_wino32<2, 8, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
     } else return 1;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return srt_launch_status();
 }

@@ -104,6 +104,7 @@ failed:
 void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4])
 {
     if (!msr) return;
+    SrtSetupLock setup;                                      // (srt_internal.h: set-up paths are serialised process-wide)
     memset(msr, 0, sizeof *msr);
     Stream* s = new (std::nothrow) Stream();
     if (!s) { stream_fail("Spleeter4StemsInit", "out of host memory"); return; }
@@ -122,8 +123,10 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { stream_fail("Spleeter4StemsInit", "no HIP device (this library has no CPU path)"); return; }
         for (int k = 0; k < 4; ++k) if (!coeffProvider || !coeffProvider[k]) { stream_fail("Spleeter4StemsInit", "null coefficient pointer"); return; }
 #define INITTRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { stream_fail("Spleeter4StemsInit", hipGetErrorString(_e)); return; } } while (0)
-        INITTRY(hipStreamCreate(&s->hop));
-        INITTRY(hipStreamCreate(&s->nn));
+        // non-blocking streams: no implicit ordering against the legacy null stream, so another instance's (another host thread's) synchronous
+        // copies and memsets during ITS Init can neither stall this instance's hops nor invalidate the graph capture of this one's pre-warm
+        INITTRY(hipStreamCreateWithFlags(&s->hop, hipStreamNonBlocking));
+        INITTRY(hipStreamCreateWithFlags(&s->nn, hipStreamNonBlocking));
         INITTRY(hipEventCreateWithFlags(&s->evMag, hipEventDisableTiming));
         INITTRY(hipEventCreateWithFlags(&s->evNN, hipEventDisableTiming));
         srt_config cfg; memset(&cfg, 0, sizeof cfg);
@@ -150,6 +153,7 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         // Pre-warm on THIS thread: the split-K workspace allocation and the capture + instantiation of one hipGraph per mask buffer
         // would otherwise happen inside the host's audio callback at hops T and 2T (an allocation and a graph build there risk a dropout).
         INITTRY(hipMemset(s->d_tmp, 0, 2 * s->hw * sizeof(float)));
+        INITTRY(hipStreamSynchronize(nullptr));               // the null-stream memsets are done before the two private (non-blocking) streams touch the buffers
         for (int b = 0; b < 2; ++b)
             if (srtPrepareForward(s->eng, s->d_tmp, 1, s->d_masks + (size_t)b * 4 * 2 * s->hw)) { stream_fail("Spleeter4StemsInit(prepare)", nullptr); return; }
         std::vector<float> ones(2 * 4 * 2 * s->hw, 1.0f), an, sy, tw(2 * FFTSIZE);                 // masks start at 1.0 (:456-467)
@@ -161,6 +165,7 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         INITTRY(hipMemcpy(s->d_swin, sy.data(), FFTSIZE * 4, hipMemcpyHostToDevice));
         INITTRY(hipMemcpy(s->d_tw, tw.data(), 2 * FFTSIZE * 4, hipMemcpyHostToDevice));
         INITTRY(hipHostMalloc((void**)&s->pinned, 2 * OUTPUTSEG * 8 * sizeof(float), hipHostMallocDefault));   // pinned queue for the per-hop D2H copy
+        INITTRY(hipStreamSynchronize(nullptr));               // masks / windows / twiddles (null-stream copies) are in place before the first hop
 #undef INITTRY
         s->outq[0] = s->pinned; s->outq[1] = s->pinned + OUTPUTSEG * 8;
     }

@@ -39,7 +39,9 @@ def test_streaming_call_latency_two_instances(tmp_path, coeffs):
         record["runs"][tag] = r
         assert len(r["instances"]) == 2
         for i, inst in enumerate(r["instances"]):
+            assert inst["init_error"] == "", "%s instance %d came up muted: %s" % (tag, i, inst["init_error"])
             o, j = inst["ordinary_hops"], inst["join_hops"]
+            assert o["p50_us"] > 20.0, "%s instance %d: calls return in %.1f us - no GPU work is being done" % (tag, i, o["p50_us"])
             assert j["n"] == hops // T and o["n"] == hops - hops // T
             assert o["p99_us"] < ORDINARY_P99_US, "%s instance %d ordinary hops: %r" % (tag, i, o)
             assert j["p99_us"] < JOIN_P99_US, "%s instance %d join hops: %r" % (tag, i, j)
