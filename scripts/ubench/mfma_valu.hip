@@ -7,6 +7,7 @@
 // Prints shader cycles (s_memtime) per MFMA for 1 and 2 waves per SIMD.      hipcc --offload-arch=gfx950 -O3 -o mfma_valu mfma_valu.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,17 +79,21 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters)
 }
 
 // G MFMAs back to back, then G*NV fillers in one burst.  KIND 0: v_add_f32, 1: ds_read_b128 (result unused), 2: LDS-DMA piece
-// (global_load_lds_dwordx4 of 1 KiB from an L2-resident buffer), 3: v_mov_b32
+// (global_load_lds_dwordx4 of 1 KiB from an L2-resident buffer), 3: v_mov_b32, 4: v_pk_add_f32 (two adds per instruction), 5: v_pk_fma_f32,
+// 6: v_pk_add_f32 with op_sel / neg modifiers (the form a register-pair Winograd transform would use)
 template <int G, int NV, int KIND>
 __global__ void __launch_bounds__(512) kb(float* out, long long* cyc, const float* src, int iters)
 {
     __shared__ __attribute__((aligned(16))) float lds[16384];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float x[8];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 xp[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+    for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 0.001f + i; xp[i] = f32x2{x[i], x[i] + 0.5f}; }
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = i;
     const float c = out[0];
+    const f32x2 cp = {c, c};
     float a = threadIdx.x * 0.5f, b = threadIdx.x * 0.25f + 1.0f;
     f32x4 acc[16];
 #pragma unroll
@@ -109,6 +114,9 @@ __global__ void __launch_bounds__(512) kb(float* out, long long* cyc, const floa
             for (int v = 0; v < (KIND == 2 ? NV : G * NV); ++v) {
                 if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[v & 7]) : "v"(c));
                 else if (KIND == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(x[v & 7]) : "v"(c));
+                else if (KIND == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp[v & 7]) : "v"(cp));
+                else if (KIND == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(xp[v & 7]) : "v"(cp));
+                else if (KIND == 6) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]" : "+v"(xp[v & 7]) : "v"(cp));
                 else if (KIND == 1) { f32x4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds0 + voff)); sink += r; }
                 else asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sp), "s"(lds0) : "memory");
             }
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(512) kb(float* out, long long* cyc, const floa
     }
     long long t1 = __builtin_readcyclecounter();
     float s = 0; for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
-    for (int i = 0; i < 8; ++i) s += x[i];
+    for (int i = 0; i < 8; ++i) s += x[i] + xp[i].x + xp[i].y;
     s += sink[0] + sink[1] + sink[2] + sink[3] + lds[threadIdx.x];
     if (s == 123.456f) out[1] = s;
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
@@ -172,8 +180,14 @@ static void run(const char* tag, int threads)
     hipFree(out); hipFree(cyc);
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "pk")) {                                   // packed fp32 VALU beside fp32 MFMA
+#define PK(G, NV) runb<G, NV, 0>("burst v_add", 512); runb<G, NV, 4>("burst v_pk_add", 512); runb<G, NV, 5>("burst v_pk_fma", 512); runb<G, NV, 6>("burst v_pk_add op_sel/neg", 512);
+        PK(1, 1) PK(4, 1) PK(8, 1) PK(8, 2) PK(16, 2)
+        runb<8, 1, 4>("burst v_pk_add", 256); runb<8, 2, 4>("burst v_pk_add", 256); runb<8, 1, 0>("burst v_add", 256);
+        return 0;
+    }
 #define ROW(NV) run<NV, 0, 0>("f32 16x16x4 + v_add per MFMA, all waves", 256); run<NV, 0, 0>("f32 16x16x4 + v_add per MFMA, all waves", 512);
     ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(6)
     run<2, 0, 1>("f32 16x16x4 + v_fma per MFMA, all waves", 256); run<2, 0, 1>("f32 16x16x4 + v_fma per MFMA, all waves", 512);

@@ -147,6 +147,16 @@ template <int I, int N> struct WinoFor {                                    // c
 };
 template <int N> struct WinoFor<N, N> { template <class F> static __device__ __forceinline__ void run(F&&) {} };
 
+// Which spatial tile a workgroup's unit is.  A workgroup walks `tpw` consecutive units; with the column walk (bit 9 of the launch's tpw argument,
+// when tpw divides the tile rows) they are `tpw` tiles of ONE tile column, top to bottom, and workgroup p + 1 - next to it on the same XCD, in step
+// with it - walks the column to its right.  A patch row is 128-byte lines of which the tile owns the middle ones; the first and last 16 bytes sit
+// in the x neighbours' lines.  Walking along x, a workgroup needs those lines again one unit (~20 us) later, when the L2 (4 MiB per XCD, ~10 us
+// of traffic) has dropped them: up5 fetched 2.8x its input from HBM.  Walking along y the x neighbours read the shared lines at the same time.
+__device__ __forceinline__ void wino_sp_xy(int sp, int tilesX, int colrun, int& tx, int& ty)
+{
+    if (colrun > 1) { const int run = sp / colrun, step = sp - run * colrun; tx = run % tilesX; ty = (run / tilesX) * colrun + step; }
+    else { tx = sp % tilesX; ty = sp / tilesX; }
+}
 // ------------------------------------------------------------------------------------------- the layer kernel
 // tile = BA x BB blocks (2 BA x 2 BB input pixels) of NI instances; BA * BB * NI == 64, BA * BB a multiple of 16.
 // Requires H even, W % 4 == 0, Cin % 4 == 0, CA % 4 == 0, Cout % 16 == 0 (the launcher checks).
@@ -201,6 +211,9 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = wave & 3, h = wave >> 2;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
+    const int walk = (tpw >> 9) & 1;                                         // column walk (wino_sp_xy)
+    tpw &= 255;
+    const int colrun = !walk ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     // A workgroup walks `tpw` consecutive (instance group, spatial tile) units of one (stem, M block): same U slabs, and the first
     // DMA of the next unit is issued BEFORE the epilogue of the current one, so its latency hides under the output transform and
     // the stores (at one workgroup per CU nothing else would cover it).  Launch order as srt_block_coord: (stem, M block) slowest.
@@ -239,7 +252,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 #pragma unroll
     for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(UR * UBUF * 4 + min(wave + 8 * i, NPP - 1) * 1024));
     auto set_dma_unit = [&](int unit) {
-        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile0 = (unit / nsp) * NI, tx0 = sx_ * TW, ty0 = sy_ * TH;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = min(wave + 8 * i, NPP - 1), e = piece * 64 + lane;
@@ -290,7 +304,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const size_t ohw = (size_t)(p.H << 1) * Wo;
     float* obase; bool blk_ok;
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile = (unit / nsp) * NI + il, a0 = sy_ * TH + 2 * ba, b0 = sx_ * TW + 2 * bb;
         blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
         obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
     };
@@ -502,13 +517,14 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int flags = tpw >> 8;                                              // (tuning aid) bit 0: static priority 1 for waves 4-7, the younger half of each SIMD pair
+    const int flags = tpw >> 8;                                              // bit 0 (tuning aid): static priority 1 for waves 4-7, the younger half of each SIMD pair; bit 1: column walk
     tpw &= 255;
     if ((flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int simd = wave & 3, hi = wave >> 2, g = simd & 1;                 // block group; class: SIMDs 0-1 C11 | C00, SIMDs 2-3 C10 | C01
     const int cls = (simd >> 1) == 0 ? (hi ? 3 : 0) : (hi ? 2 : 1);
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int MB2 = p.Cout / 32, MB = p.Cout / 16;
+    const int colrun = !(flags & 2) ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;      // workgroups per (stem, M-block pair)
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
     const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
@@ -550,7 +566,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         return u;
     };
     auto unit_voff = [&](int unit) {
-        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile0 = (unit / nsp) * NI, tx0 = sx_ * TW, ty0 = sy_ * TH;
         const int e = (lpiece - NUP) * 64 + lane;
         const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
@@ -592,7 +609,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const size_t ohw = (size_t)(p.H << 1) * Wo;
     float* obase; bool blk_ok;
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, a0 = (sp / tilesX) * TH + 2 * ba, b0 = (sp % tilesX) * TW + 2 * bb;
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile = (unit / nsp) * NI + il, a0 = sy_ * TH + 2 * ba, b0 = sx_ * TW + 2 * bb;
         blk_ok = tile < p.ntiles && a0 < p.H && b0 < p.W;
         obase = p.outAct + stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? 2 * a0 : 0) * Wo + (blk_ok ? 2 * b0 : 0);
     };
@@ -821,6 +839,9 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int MB2 = p.Cout / 32, MB = p.Cout / 16;
+    const int walk = (tpw >> 9) & 1;                                         // column walk (wino_sp_xy)
+    tpw &= 255;
+    const int colrun = !walk ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
     const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
@@ -858,7 +879,8 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     };
     // patch float4 e = ((c * NI + ii) * PH + row) * PR4 + j  <-  channel 4k+c, instance tile0+ii, input row 4 ty0 - 1 + row, columns 4 tx0 - 4 + 4j .. +3
     auto patch_voff = [&](int unit, int piece) {
-        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * BB, ty0 = (sp / tilesX) * BA;     // tile origin in BLOCKS
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile0 = (unit / nsp) * NI, tx0 = sx_ * BB, ty0 = sy_ * BA;     // tile origin in BLOCKS
         const int e = piece * 64 + lane;
         const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
         const int gy = 4 * ty0 - 1 + row, gx = 4 * tx0 - 4 + 4 * j;
@@ -906,7 +928,8 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     const size_t ohw = (size_t)Ho * Wo;
     size_t obase; bool blk_ok;
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = (unit / nsp) * NI + il, oy0 = (sp / tilesX) * TH + 2 * ba, ox0 = (sp % tilesX) * TW + 2 * bb;
+        int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
+        const int tile = (unit / nsp) * NI + il, oy0 = sy_ * TH + 2 * ba, ox0 = sx_ * TW + 2 * bb;
         blk_ok = tile < p.ntiles && oy0 < Ho && ox0 < Wo;                    // (Ho, Wo even: a block is inside the image or outside it)
         obase = stem * p.out_stem + (blk_ok ? tile : 0) * p.out_tile + (size_t)(blk_ok ? oy0 : 0) * Wo + (blk_ok ? ox0 : 0);
     };
@@ -1115,6 +1138,18 @@ static int wino_tpw(long wgs, long units)
     while (tpw < 8 && wgs / (2 * tpw) >= 512 && units % (2 * tpw) == 0) tpw *= 2;
     return tpw;
 }
+// bit 9 of the kernels' tpw argument: the units of a workgroup walk down a tile column (wino_sp_xy).  SRT_TUNE=winowalk=0|1 in tuning builds.
+#ifndef SRT_WINO_WALK_DEFAULT
+#define SRT_WINO_WALK_DEFAULT 1
+#endif
+static int wino_walk_bit()
+{
+#ifdef SRT_TUNING
+    const int v = wino_tune("winowalk=");
+    if (v >= 0) return v ? 512 : 0;
+#endif
+    return SRT_WINO_WALK_DEFAULT ? 512 : 0;
+}
 // Layers with a multiple of 32 output channels (up2..up4) run the 32-channel workgroup, srt_dec_wino32, in the arrangement measured
 // fastest at 64 tiles x 4 stems: rings of three, fenced VALU bursts, staggered wave pairs, the units of a
 // workgroup as one continuous K stream.  SRT_TUNE=wino32=0|1 and winocfg=<n> select the other measured arrangements in tuning builds.
@@ -1138,7 +1173,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
     if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 16 && p.W < 32 && wino32_on()) {     // 4 x 16 .. 28 inputs (up1 of 256 x 1024 tiles): two instances per workgroup
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
-        SRT_LAUNCH((srt_dec_wino32<2, 8, 0, 3, 2, 1, 1, 0, 1, 1, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino32<2, 8, 0, 3, 2, 1, 1, 0, 1, 1, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
         return srt_launch_status();
     }
     if (p.Cout % 32 == 0 && p.Cin >= 32 && p.H >= 4 && p.W >= 32 && wino32_on()) {      // (Cin >= 32: at least 8 K steps, the continuous stream looks D + 1 = 3 steps ahead)
@@ -1147,7 +1182,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const dim3 grid((unsigned)(wgs / tpw));
 #ifdef SRT_TUNING
         if (wino_tune("winoprio=") > 0) tpw |= 256;
-#define W32(...) do { SRT_LAUNCH((srt_dec_wino32<2, 16, __VA_ARGS__>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; } while (0)
+#define W32(...) do { SRT_LAUNCH((srt_dec_wino32<2, 16, __VA_ARGS__>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; } while (0)
         switch (wino_tune("winoabl=")) {                                     // ablations of the shipped arrangement (wrong results, timing only)
         case 1: W32(1, 3, 2, 1, 1, 0, 1, 1);
         case 3: W32(3, 3, 2, 1, 1, 0, 1, 1);
@@ -1167,7 +1202,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         }
 #undef W32
 #endif
-        SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
         return srt_launch_status();
     }
     if (p.H >= 8 && p.W >= 32) {
@@ -1176,26 +1211,26 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         const dim3 grid((unsigned)(wgs / tpw));
 #ifdef SRT_TUNING
         switch (wino_tune("winoabl=")) {
-        case 1: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 2: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 3: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 1: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 2: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 3: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         }
-        if (wino_tune("winosb=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
-        if (wino_tune("winocs=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
-        if (wino_tune("winocs=") == 2) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0; }
+        if (wino_tune("winosb=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
+        if (wino_tune("winocs=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
+        if (wino_tune("winocs=") == 2) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
         switch (wino_tune("winoring=")) {
-        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
-        case 6: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 6>), grid, dim3(512), 0, s, p, U, u_stem, tpw); return 0;
+        case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 6: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 6>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         }
 #endif
-        SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, SRT_WINO_RING>), grid, dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, SRT_WINO_RING>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
     } else if (p.H >= 4 && p.W >= 16) {
         const long units = (long)((p.W + 15) / 16) * ((p.H + 3) / 4) * ((p.ntiles + 3) / 4), wgs = units * MB * p.nstems;
         const int tpw = wino_tpw(wgs, units);
-        SRT_LAUNCH((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_dec_wino<2, 8, 4>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
     } else return 1;
     return srt_launch_status();
 }
@@ -1221,11 +1256,11 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
     if (Ho >= 4 && Wo >= 32) {
         const long units = (long)((Wo + 31) / 32) * ((Ho + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
-        SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
     } else if (Ho >= 4 && Wo >= 16) {
         const long units = (long)((Wo + 15) / 16) * ((Ho + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
-        SRT_LAUNCH((srt_enc_wino32<2, 8, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw);
+        SRT_LAUNCH((srt_enc_wino32<2, 8, 2>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
     } else return 1;
     return srt_launch_status();
 }
