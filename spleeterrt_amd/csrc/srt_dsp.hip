@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) srt_stft_kernel(const SrtStftParams p,
 
     // the windowed samples of the NEXT frame are loaded while the current frame is transformed (clamped frame index:
     // a redundant reload at the end of the run instead of a conditional assignment of the 16 staged values)
-    cf nxt[16];
+    float nxtL[16], nxtR[16];                            // raw samples: fetch only ISSUES loads, the window multiply happens where they are consumed
     float aw[16];                                        // this thread's 16 analysis-window taps are the same for every frame
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) aw[n2] = p.tab.preWin[tid + 256 * n2];
@@ -201,42 +201,24 @@ __global__ void __launch_bounds__(256, 2) srt_stft_kernel(const SrtStftParams p,
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int n = tid + 256 * n2;
-            const bool ok = pos + n < p.nsamples;                        // tail frame is zero padded (stftFix.c:460-472)
-            const size_t q = ok ? pos + n : 0;
-            nxt[n2] = f2(p.L[q], p.R[q]) * (ok ? aw[n2] : 0.f);
+            const size_t q = pos + n < p.nsamples ? pos + n : 0;
+            nxtL[n2] = p.L[q]; nxtR[n2] = p.R[q];
         }
     };
     const int flast = max(p.frames_computed, 1) - 1;
     cf* e1 = bufA;
     cf* e2 = bufB;
-    fetch(min((int)(blk * fpb), flast));
-    for (int fi = 0; fi < fpb; ++fi) {
-        const int f = blk * fpb + fi;
-        if (f >= p.rows_total) break;
+    // Output rows of frame f (spectra of both channels + the magnitude tile row): written in iteration f + 1, after that iteration has taken
+    // its prefetched samples and before it requests the samples of frame f + 2.  vmcnt counts loads and stores in one queue: a wait for
+    // loads also waits for every store issued BEFORE them, and the compiler's count for stores issued after them is conservative across the
+    // lane-conditional blocks below - so stores right ahead of a load wait cost their acknowledgement time once per frame.  Issued ahead of
+    // the next prefetch they have a whole transform to complete.
+    auto emit = [&](int f, const cf* nat) {
         const int tile = f / p.T, t = f % p.T;
         float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
         float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
         cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
         cf* specR = specL + p.spec_ch_stride;
-        if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
-            for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
-            if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
-            continue;
-        }
-        cf v[16];
-#pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) v[n2] = nxt[n2];
-        fetch(min(f + 1, flast));
-        // exchange 1 in e1, exchange 2 in e2, natural-order result back in e1 (free once exchange 1 has been read).  The two
-        // buffers swap roles every frame: the next frame's exchange 1 goes where this frame's exchange 2 was (all of its reads
-        // precede the barrier below), and its exchange 2 - written behind the transform's first barrier - goes where this
-        // frame's epilogue reads from.
-        fft4096_pp(v, e1, e2, twa, s_twb, tid);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) e1[tid + 256 * k2] = v[FFT16_AT(k2)];
-        __syncthreads();
-        const cf* nat = e1;
-        { cf* t = e1; e1 = e2; e2 = t; }
         // separate the two real spectra; stored spectrum = conj(F) (the reference's re/im convention)
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
@@ -255,7 +237,47 @@ __global__ void __launch_bounds__(256, 2) srt_stft_kernel(const SrtStftParams p,
                 specR[k] = f2(0.f, 0.f);
             }
         }
+    };
+    int pend = -1;                                       // frame whose natural-order result waits in `nat` (LDS)
+    const cf* nat = nullptr;
+    fetch(min((int)(blk * fpb), flast));
+    for (int fi = 0; fi < fpb; ++fi) {
+        const int f = blk * fpb + fi;
+        if (f >= p.rows_total) break;
+        if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
+            if (pend >= 0) { emit(pend, nat); pend = -1; }
+            const int tile = f / p.T, t = f % p.T;
+            float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
+            float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
+            cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
+            cf* specR = specL + p.spec_ch_stride;
+            for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
+            if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
+            continue;
+        }
+        cf v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const bool ok = (size_t)f * SRT_HOP + tid + 256 * n2 < p.nsamples;   // tail frame is zero padded (stftFix.c:460-472)
+            v[n2] = f2(nxtL[n2], nxtR[n2]) * (ok ? aw[n2] : 0.f);
+        }
+        // every load of this frame's samples has returned before the first store below is issued (and the compiler's wait bookkeeping knows
+        // it: without the explicit wait it moves the multiplies above, with their waits, behind the stores)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (pend >= 0) emit(pend, nat);                  // (its LDS reads precede this frame's first transform barrier; the buffer is rewritten behind it)
+        fetch(min(f + 1, flast));
+        // exchange 1 in e1, exchange 2 in e2, natural-order result back in e1 (free once exchange 1 has been read).  The two
+        // buffers swap roles every frame: the next frame's exchange 1 goes where this frame's exchange 2 was (all of its reads
+        // precede the barrier below), and its exchange 2 - written behind the transform's first barrier - goes where this
+        // frame's output rows are read from.
+        fft4096_pp(v, e1, e2, twa, s_twb, tid);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) e1[tid + 256 * k2] = v[FFT16_AT(k2)];
+        __syncthreads();
+        nat = e1; pend = f;
+        { cf* t = e1; e1 = e2; e2 = t; }
     }
+    if (pend >= 0) emit(pend, nat);
 }
 
 int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
@@ -328,6 +350,20 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
     for (int k2 = 0; k2 < 16; ++k2) pw[k2] = p.tab.postWin[tid + 256 * k2];
     const int f0 = max(s0 - 3, 0);                      // frames before 0 do not exist: the window simply starts empty
     if (f0 < p.frames) fetch(f0);
+    // Segment f is complete once frame f has been added, but it is WRITTEN in iteration f + 1, right before that iteration requests the rows of
+    // frame f + 2: vmcnt counts loads and stores in one queue, so the wait for a frame's rows also waits for every store issued before them -
+    // stores issued just ahead of the wait (the end of the previous iteration, where this code stood in rounds 1-2) cost their full
+    // acknowledgement time (~1-2 us) once per frame; issued ahead of the NEXT prefetch they have a whole FFT to complete.
+    auto emit_and_slide = [&](int seg) {
+        if (seg >= s0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { oL[(size_t)seg * SRT_HOP + tid + 256 * j] = acc[0][j].y; oR[(size_t)seg * SRT_HOP + tid + 256 * j] = acc[0][j].x; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                   // slide the window
+            acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j]; acc[3][j] = f2(0.0f, 0.0f);
+        }
+    };
     for (int f = f0; f < s1; ++f) {
         if (f < p.frames) {                             // workgroup-uniform; false only for the last three segments of the stream
             // staging into sx: its last readers (exchange 1 of the previous frame, when it was `sy`) all passed that frame's
@@ -351,6 +387,8 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
             cf v[16];
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) v[n2] = sx[tid + 256 * n2];
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // all of this frame's rows have arrived (also the ones only lane 0 uses): nothing below waits on the stores
+            if (f > f0) emit_and_slide(f - 1);
             fetch(min(f + 1, p.frames - 1));            // the staging registers are free again: next frame's rows fly under this FFT
             // exchange 1 in sy (free: its previous contents, the previous frame's exchange 2, were read before the barrier above),
             // exchange 2 back in sx (every thread has read its staged values before the transform's first barrier)
@@ -360,16 +398,9 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
                 acc[k2 >> 2][k2 & 3] = __builtin_elementwise_fma(v[FFT16_AT(k2)], f2(pw[k2], pw[k2]), acc[k2 >> 2][k2 & 3]);   // swapped back: L = .y, R = .x
             }
             { cf* t = sx; sx = sy; sy = t; }            // next frame stages where this frame's exchange 1 was (read before the second barrier)
-        }
-        if (f >= s0) {                                  // segment f is complete: emit it
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { oL[(size_t)f * SRT_HOP + tid + 256 * j] = acc[0][j].y; oR[(size_t)f * SRT_HOP + tid + 256 * j] = acc[0][j].x; }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                   // slide the window
-            acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j]; acc[3][j] = f2(0.0f, 0.0f);
-        }
+        } else if (f > f0) emit_and_slide(f - 1);
     }
+    if (s1 > f0) emit_and_slide(s1 - 1);                // the last segment of the run
 }
 
 int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)

@@ -15,6 +15,7 @@
 //   * global->LDS staging is register-prefetched one K-chunk ahead so HBM/L2 latency hides under the MFMAs.
 // The naive kernels are a bit-simple cross-check path (SRT_IMPL_NAIVE) and serve layers not yet on MFMA.
 #include "srt_device.h"
+#include <type_traits>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------- activations
@@ -714,6 +715,138 @@ __global__ void __launch_bounds__(256, OCC) srt_up6_kernel(const SrtConvParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------- up6, streamed down a tile column
+// The kernel above asks HBM for its input one dword per lane, 320 row pieces of 264 bytes per workgroup: those loads alone take 0.62 ms of its
+// 0.74 (scripts/ubench/tile_reads.hip); the same bytes as aligned 16-byte row segments take 0.43.  This form moves the input by LDS-DMA only
+// (buffer_load_dwordx4 ... lds: 16 bytes per lane, zeros outside the image, no registers in flight) and overlaps it with the arithmetic by
+// construction: a workgroup owns a TW-pixel wide column of one instance and walks down it CR input rows at a time,
+//   interval i:   DMA   rows of chunk i+1 (32 channels x CR rows x (TW+8) floats)      -> patch buffer (i+1) & 1
+//                 MFMA  chunk i: col[tap][pixel] = sum_ci w[ci][tap] x[ci][pixel]      -> ring of 3 CR rows of tap planes in LDS
+//                 gather the 2x2 output quads of input rows CR(i-1)-1 .. CR i-2 from the ring (their three tap rows are complete), epilogue, store
+// with ONE barrier per interval.  No input row is fetched twice by a workgroup (no y halo), the x halo is the 16 bytes either side that sit in
+// the neighbour column's lines, read by the neighbouring workgroup at the same time on the same XCD.  Sums in the order of the kernel above
+// (channels ascending in the MFMA chain, taps ascending in the gather): bit-identical results.
+typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
+template <int TW, int CR, int ABL = 0>                                      // ABL (tuning builds, wrong results): 1 no DMA, 2 DMA only, 3 no gather
+__global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvParams p)
+{
+    constexpr int CIN = 32, CAH = 16;
+    constexpr int PW = TW + 2, SEG = TW / 4 + 2, PROW = SEG * 4;             // pixels of a chunk row incl. halo; float4 segments per row (from tx0 - 4)
+    constexpr int CHF4 = CR * SEG, NF4 = CIN * CHF4, NPIECE = NF4 / 64, NWAVE = 8, NDW = 4, PPW = (NPIECE + NDW - 1) / NDW;
+    static_assert(NF4 % 64 == 0 && (CAH * CHF4) % 64 == 0, "a DMA piece (64 lanes x 16 B) must not straddle the two source tensors");
+    static_assert(TW == 64 && 2 * CR <= NWAVE, "gather: a wave per (row of the chunk, output row parity), a lane per pixel");
+    constexpr int PBUF = CIN * CR * PROW;
+    constexpr int RR = 2 * CR + 2, RWP = 72;                                  // ring rows; row pitch of a tap plane (4 * RWP = 32 mod 64 banks: the two lane halves write disjoint banks)
+    static_assert(RWP >= PW, "ring pitch");
+    constexpr int NPIX = CR * PW, NG = (NPIX + 31) / 32;
+    static_assert(NG <= NWAVE && 2 * CR == NWAVE - NDW, "one pixel group per wave; waves NDW.. gather");
+    __shared__ __attribute__((aligned(16))) float s_all[2 * PBUF + RR * 25 * RWP];
+    float* s_p = s_all;
+    float* s_r = s_all + 2 * PBUF;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (p.W + TW - 1) / TW;
+    const int pos = srt_xcd_order(tilesX * p.nstems * p.ntiles), tx0 = (pos % tilesX) * TW, inst = pos / tilesX;
+    const int stem = inst / p.ntiles, tile = inst % p.ntiles;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const float* w = p.wraw + stem * p.coeff_stem;                            // [Cin][1][25]
+    float a[CIN / 2];
+#pragma unroll
+    for (int cp = 0; cp < CIN / 2; ++cp) {
+        const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
+        a[cp] = l31 < 25 ? v : 0.0f;
+    }
+    // ---- DMA: float4 e = (ch * CR + row) * SEG + j of a chunk <- channel ch, image row CR i + row, columns tx0 - 4 + 4 j .. + 3; wave w moves pieces w, w + 4, ...
+    constexpr unsigned OOR = 0x80000000u;
+    unsigned c0[PPW]; int prow[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = min(wave + NDW * q, NPIECE - 1), e = piece * 64 + lane;
+        const int j = e % SEG, row = (e / SEG) % CR, chl = (e / CHF4) % CAH, gx = tx0 - 4 + 4 * j;
+        prow[q] = row;
+        c0[q] = (gx >= 0 && gx + 3 < p.W) ? 4u * (unsigned)((size_t)chl * hw + (size_t)row * p.W + gx) : OOR;
+    }
+    const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile * p.srcB_tile);
+    srt_i32x4 rsA, rsB;
+    rsA.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba_); rsA.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba_ >> 32) & 0xffffu));
+    rsB.x = __builtin_amdgcn_readfirstlane((int)(unsigned)bb_); rsB.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(bb_ >> 32) & 0xffffu));
+    rsA.z = rsB.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)4 * CAH * hw); rsA.w = rsB.w = 0x00020000;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
+    auto dma_chunk = [&](int i) {
+        const unsigned adv = 4u * (unsigned)(i * CR * p.W), base = lds0 + (unsigned)((i & 1) * PBUF * 4);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int piece = min(wave + NDW * q, NPIECE - 1);                // wave-uniform (a piece past the last one repeats it)
+            const unsigned voff = (c0[q] != OOR && i * CR + prow[q] < p.H) ? c0[q] + adv : OOR;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(piece * 1024));
+            if (piece < NPIECE / 2) asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsA), "s"(dst) : "memory");
+            else asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsB), "s"(dst) : "memory");
+        }
+    };
+    for (int e = tid; e < RR * 25 * RWP; e += 64 * NWAVE) s_r[e] = 0.0f;          // rows above the image (and every slot before its first use)
+    const int nchunks = (p.H + CR - 1) / CR + 1;                             // the last chunk lies below the image: zeros, the bottom halo row
+    if (ABL != 1 && wave < NDW) dma_chunk(0);
+    const float bi = p.bias[stem * p.coeff_stem], sc = p.bnScale[stem * p.coeff_stem], sf = p.bnShift[stem * p.coeff_stem];
+    const int Wo = p.W << 1;
+    float* out = p.outAct + stem * p.out_stem + tile * p.out_tile;
+    int slot0 = 0;                                                           // ring slot of image row CR i
+    for (int i = 0; i <= nchunks; ++i) {
+        if (wave < NDW) __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's pieces of chunk i.  (The gather waves never wait for their stores.)
+        __syncthreads();
+        if (ABL != 1 && wave < NDW && i + 1 < nchunks) dma_chunk(i + 1);
+        const int grp = wave < NDW ? wave : NDW + ((wave - i) & (NWAVE - NDW - 1));   // groups NDW.. go round the gather waves (one SIMD each) interval by interval
+        if (ABL != 2 && i < nchunks && grp < NG) {                            // wave-uniform
+            const int pix = min(grp * 32 + l31, NPIX - 1), row = pix / PW, col = pix % PW;
+            const float* bsrc = s_p + (i & 1) * PBUF + (half * CR + row) * PROW + col + 3;
+            float b[CIN / 2];
+#pragma unroll
+            for (int cp = 0; cp < CIN / 2; ++cp) b[cp] = bsrc[cp * 2 * CR * PROW];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+            int slot = slot0 + row; slot = slot >= RR ? slot - RR : slot;
+            if (grp * 32 + l31 < NPIX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (tap < 25) s_r[(slot * 25 + tap) * RWP + col] = acc[r];
+                }
+            }
+        }
+        // gather: a wave per (row of the chunk, output row parity), a lane per pixel
+        const int gw = wave - NDW;
+        const int b0 = lane, a0 = gw % CR, py = gw / CR;
+        const int g = CR * (i - 1) - 1 + a0, gb = tx0 + b0;                  // input row whose output row 2 g + py this thread emits
+        auto gather = [&](auto pyc) __attribute__((always_inline)) {
+            constexpr int PY = decltype(pyc)::value;
+            int sm = slot0 - CR - 2 + a0; sm = sm < 0 ? sm + RR : sm;        // ring slots of rows g - 1, g, g + 1
+            const int s1 = sm + 1 >= RR ? sm + 1 - RR : sm + 1, s2 = s1 + 1 >= RR ? s1 + 1 - RR : s1 + 1;
+            const float* r0 = s_r + sm * 25 * RWP + b0 + 1;
+            const float* r1 = s_r + s1 * 25 * RWP + b0 + 1;
+            const float* r2 = s_r + s2 * 25 * RWP + b0 + 1;
+            float o[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {                              // ascending (ky, kx): the reference's col2im order
+                const int ky = tap / 5, kx = tap % 5;
+                if (((ky + 1) & 1) != PY) continue;
+                const int px = (kx + 1) & 1, dy = (PY + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+                o[px] += (dy < 0 ? r0 : dy == 0 ? r1 : r2)[tap * RWP + dx];
+            }
+            float2 v;
+            v.x = srt_dec_epilogue(o[0], bi, sc, sf, actp);
+            v.y = srt_dec_epilogue(o[1], bi, sc, sf, actp);
+            *reinterpret_cast<float2*>(out + (size_t)(2 * g + PY) * Wo + 2 * gb) = v;
+        };
+        if (ABL < 2 && gw >= 0 && g >= 0 && g < p.H && gb < p.W) {
+            if (py) gather(std::integral_constant<int, 1>{}); else gather(std::integral_constant<int, 0>{});
+        }
+        slot0 += CR; slot0 = slot0 >= RR ? slot0 - RR : slot0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- dispatch
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 static int launch_enc_cfg(const SrtConvParams& p, hipStream_t s)
@@ -755,6 +888,9 @@ int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
     return launch_enc_cfg<64, 2, 16, 1, 2, 4, 4>(p, s);                                      // down6 class (4 instances of 4x16)
 }
 
+#ifndef SRT_UP6_STREAM_DEFAULT
+#define SRT_UP6_STREAM_DEFAULT 1
+#endif
 int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
     if ((p.in16 || p.out16) && !(impl == 0 && p.Cout == 1 && p.Cin == 32 && !p.out16)) return -1;   // only up6 reads fp16 tensors here
@@ -765,6 +901,22 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 #ifdef SRT_TUNING
         const char* tv = getenv("SRT_TUNE_UP6");
         v = tv ? atoi(tv) : 0;
+#endif
+        // fp32 tensors, batches that fill the chip with column workgroups (2 per CU): the streamed form
+        const long cols = (long)((p.W + 63) / 64) * p.nstems * p.ntiles;
+        if (!p.in16 && p.CA == 16 && p.W % 4 == 0 && p.srcA && p.srcB && (size_t)64 * p.H * p.W < 0x7fffffffu && ((cols >= 512 && v == 0 && SRT_UP6_STREAM_DEFAULT) || v == 11)) {
+            SRT_LAUNCH((srt_up6_stream_kernel<64, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);
+            return srt_launch_status();
+        }
+#ifdef SRT_TUNING
+        if (v >= 12 && v <= 14) {
+            if (v == 12) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 1>), dim3((unsigned)cols), dim3(512), 0, s, p);
+            if (v == 13) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);
+            if (v == 14) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 3>), dim3((unsigned)cols), dim3(512), 0, s, p);
+            return srt_launch_status();
+        }
+#endif
+#ifdef SRT_TUNING
         if (v == 1) UP6_LAUNCH(16, 32);
         else if (v == 5) UP6_LAUNCH(8, 32);
         else if (v == 3) UP6_LAUNCH(4, 64);
@@ -776,9 +928,9 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         else if (v == 9) UP6_LAUNCH_OCC(16, 16, 4);         // 18 x 18 = 324 pixels: 11 sub-tiles, 35 KB
 #undef UP6_LAUNCH_OCC
 #endif
-        if (v > 5) {}
+        if (v > 5 && v < 10) {}
         else if (v == 0 && p.in16) SRT_LAUNCH((srt_up6_kernel<8, 64, 32, true>), dim3(((p.W + 63) / 64) * ((p.H + 7) / 8) * p.nstems * p.ntiles), dim3(256), 0, s, p);
-        else if (v == 0) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
+        else if (v == 0 || v >= 10) UP6_LAUNCH(8, 64);                // measured (XCD order, loads up front): 16x32 0.73 ms, 8x64 0.74, 8x32 0.75, 4x128 0.84, 4x64 0.86
 #undef UP6_LAUNCH
         return srt_launch_status();
     }

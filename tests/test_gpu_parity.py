@@ -163,6 +163,35 @@ def test_winograd_decoder_odd_geometries(oracle, coeffs, T, F, ntiles, stems, ch
         T, F, ntiles, stems, worst[0], worst[1], {k: v for k, v in ks.items() if k.startswith("up")}))
 
 
+@pytest.mark.parametrize("T,F,ntiles,stems", [
+    (64, 512, 33, 4),       # up6 input 32 x 256: four full 64-pixel columns, 132 instances (odd tile count)
+    (64, 576, 29, 4),       # 32 x 288: a 32-pixel last column (W % 64 != 0): the right image edge inside a DMA piece
+    (128, 320, 43, 4),      # 64 x 160: three columns, the last one half empty; 32 chunks per column
+])
+def test_up6_streamed_form(oracle, coeffs, T, F, ntiles, stems):
+    """Batches that fill the chip with 64-pixel column workgroups run up6 as srt_up6_stream_kernel (csrc/srt_nn.hip: LDS-DMA input, one
+    workgroup streams down a column, ring of tap rows).  Every tensor of the first, an interior and the last tile of the first and the last
+    stem against the oracle, at the tolerance of the other kernels; the engine must report the streamed kernel for up6."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, impl=srt.IMPL_MFMA)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=900 + T + F)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    assert np.isfinite(masks).all()
+    worst = (0.0, 0.0)
+    for s in (0, stems - 1):
+        for t in sorted({0, ntiles // 2, ntiles - 1}):
+            worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, "up6 stream T=%d F=%d" % (T, F)))
+    ks = _layer_kernels(eng, xd)
+    assert ks["up6"].startswith("srt_up6_stream_kernel"), ks["up6"]
+    eng.close()
+    print("up6 streamed %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
+
+
 def test_forward_lut_variant(oracle, coeffs):
     import torch
     import spleeterrt_amd as srt
