@@ -512,6 +512,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
     constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;                // DMA pieces per K step, per wave (the tail repeats the last piece)
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
+    __shared__ __attribute__((aligned(16))) float s_epi[96];                   // bias | BN scale | BN shift of the workgroup's 32 channels
     float* s_u = s_all;
     float* s_p = s_all + UR * UBUF;
 
@@ -529,6 +530,10 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
     const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
     const int m0 = mblk2 * 32;
+    if (tid < 32) {                                                          // (visible after the first barrier of the K stream)
+        const size_t ci = stem * p.coeff_stem + m0 + tid;
+        s_epi[tid] = p.bias[ci]; s_epi[32 + tid] = p.bnScale[ci]; s_epi[64 + tid] = p.bnShift[ci];
+    }
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* up = U + stem * u_stem + (size_t)(2 * mblk2) * UB1;         // K step k at + k * MB * UB1
@@ -758,12 +763,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         auto emit = [&](auto act) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                float bi[4], sc[4], sf[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t ci = stem * p.coeff_stem + m0 + 16 * mb + 4 * kq + r;
-                    bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
-                }
+                // (constants out of LDS: global loads here would sit between the stores of the two M blocks, and a wait for a load also waits for
+                //  every store issued before it - one store round trip per unit)
+                const float4 bi4 = *reinterpret_cast<const float4*>(&s_epi[16 * mb + 4 * kq]), sc4 = *reinterpret_cast<const float4*>(&s_epi[32 + 16 * mb + 4 * kq]),
+                             sf4 = *reinterpret_cast<const float4*>(&s_epi[64 + 16 * mb + 4 * kq]);
+                const float bi[4] = { bi4.x, bi4.y, bi4.z, bi4.w }, sc[4] = { sc4.x, sc4.y, sc4.z, sc4.w }, sf[4] = { sf4.x, sf4.y, sf4.z, sf4.w };
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float m[NP];
@@ -1033,6 +1037,14 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         if (flex_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
         dma_patch(min(D, nk - 1), D % UR);
         int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;
+        // epilogue constants of this lane's two output channels, before the K stream: loaded in the epilogue they sat between its stores, and a wait
+        // for a load also waits for every store issued before it (three store round trips per unit)
+        float ebias[2], esc[2], esf[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const size_t ci = stem * p.coeff_stem + m0 + 16 * mb + 4 * kq + CLS;
+            ebias[mb] = p.bias[ci]; esc[mb] = p.outAct ? p.bnScale[ci] : 0.0f; esf[mb] = p.outAct ? p.bnShift[ci] : 0.0f;
+        }
         for (int t = 0; t < tpw; ++t) {
         for (int k = 0; k < nk; ++k) {
             // vmcnt: everything older than this wave's last step of pieces has landed (U slab k, patch k+1); the prologue's extra patch pieces are older still
@@ -1061,7 +1073,7 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) c4[c] = *reinterpret_cast<const float4*>(&s_x[((((c * 2 + g) * 16) + ch) * 16 + l15) * 4]);
                 const int co = m0 + 16 * mb + ch;
-                const float bias = p.bias[stem * p.coeff_stem + co];
+                const float bias = ebias[mb];
                 float o[4];
                 o[0] = ((c4[0].x + c4[1].x) + (c4[2].x + c4[3].x)) + bias; o[1] = ((c4[0].y + c4[1].y) + (c4[2].y + c4[3].y)) + bias;
                 o[2] = ((c4[0].z + c4[1].z) + (c4[2].z + c4[3].z)) + bias; o[3] = ((c4[0].w + c4[1].w) + (c4[2].w + c4[3].w)) + bias;
@@ -1070,7 +1082,7 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
                     *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
                     *reinterpret_cast<float2*>(dst + Wo) = make_float2(o[2], o[3]);
                     if (p.outAct) {
-                        const float sc = p.bnScale[stem * p.coeff_stem + co], sf = p.bnShift[stem * p.coeff_stem + co];
+                        const float sc = esc[mb], sf = esf[mb];
                         float* da = p.outAct + obase + (size_t)co * ohw;
                         *reinterpret_cast<float2*>(da) = make_float2(srt_enc_epilogue(o[0], sc, sf, actp), srt_enc_epilogue(o[1], sc, sf, actp));
                         *reinterpret_cast<float2*>(da + Wo) = make_float2(srt_enc_epilogue(o[2], sc, sf, actp), srt_enc_epilogue(o[3], sc, sf, actp));
