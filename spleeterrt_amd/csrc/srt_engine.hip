@@ -483,6 +483,15 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                     p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
                 }
             } else act_ready = false;
+            // a direct layer in front of the first Winograd-form one writes that copy itself (srt_enc_mfma2, second fp32 output): one more store per
+            // element instead of a pass that reads the tensor back.  Only the plain MFMA kernel does that (not the split-K one of small batches).
+            const bool next_wino = !few && i > 0 && i + 1 < 6 && e->wino_e[i + 1] && e->act32[i] && !e->act16;
+            bool producer_copy = false;
+            if (!ewino && next_wino && e->cfg.impl == SRT_IMPL_MFMA && !small && srt_enc_producer_copy()) {
+                p.outAct = e->act32[i] + (size_t)s0 * ntiles * e->raw_tile[i];
+                p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
+                producer_copy = true;
+            }
             snprintf(nm, sizeof nm, "down%d", i + 1);
             TimerScope ts(e, nm);
             int rc2 = 1;
@@ -496,7 +505,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 rc2 = srt_launch_enc_f16(p, e->stream);
             }
             if (e->act16 && i > 0 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for an encoder layer");
-            if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_enc2(p, e->stream);
+            if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) { rc2 = srt_launch_enc2(p, e->stream); if (rc2 == 0 && producer_copy) act_ready = true; }
             if (rc2 < 0) return fail(-2, "encoder launch failed");
             if (rc2 == 1 && srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
         }

@@ -114,6 +114,7 @@ void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s
 int  srt_launch_pack_wino(const float* w, float* u, int Cin, int Cout, hipStream_t s);
 int  srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s);
 // encoder layers in Winograd form (srt_nn4.hip, srt_enc_wino32): U from the OIHW weights; the layer reads act(BN(raw)) of its input (srcA) and
+int srt_enc_producer_copy();          // tuning builds: SRT_TUNE=...,enccopy=0 keeps the separate bn+act pass in front of the first Winograd-form encoder layer
 // writes raw (outRaw) + optionally its own act(BN(.)) copy (outAct with bnScale / bnShift).  srt_enc_wino_covers: geometry test of the launcher.
 int  srt_launch_pack_wino_enc(const float* w, float* u, int Cin, int Cout, hipStream_t s);
 int  srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s);

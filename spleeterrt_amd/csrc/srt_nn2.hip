@@ -274,6 +274,14 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
         }
         __syncthreads();
     }
+    // fp32 second output (the layer in front of the first Winograd-form encoder layer, csrc/srt_nn4.hip): act(BN(raw)) beside raw, the input the
+    // next layer reads.  Its BN constants wait in two registers of the first BM threads and move into the s_ibn rows once the K loop is done with them.
+    const bool act32 = !STEMSTACK && !SPLITK && !DUAL && !p.out16 && p.outAct != nullptr && p.bnScale != nullptr;
+    float osc = 0.0f, osf = 0.0f;
+    if (act32 && tid < BM) {
+        const size_t ci = stem * p.coeff_stem + min(m0 + tid, p.Cout - 1);
+        osc = p.bnScale[ci]; osf = p.bnShift[ci];
+    }
     // split-K: this workgroup runs the chunks [chA, chB) of the K loop (all of them in a plain launch)
     const int nchunks_all = p.Cin / KC;
     const int cps = SPLITK ? (nchunks_all + p.ksplit - 1) / p.ksplit : nchunks_all;
@@ -316,6 +324,11 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
     }
 
     if (ABL == 7) return;                                  // ablation: no epilogue
+    if (!STEMSTACK && act32) {                             // (the last loop barrier is behind every reader of s_ibn)
+        if (tid < BM) { s_ibn[tid] = osc; s_ibn[SRT_ENC_MAX_CIN + tid] = osf; }
+        __syncthreads();
+    }
+    const SrtAct ap32 = srt_act_params(srt_act_kind(p, stem), p.variant);
     // epilogue: conv + bias, stored ONCE (the skip tensor is also the next layer's input; see store_patch)
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
@@ -331,6 +344,7 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
             const int st = STEMSTACK ? m / p.Cout : stem, co = STEMSTACK ? m % p.Cout : m;
             bi[r] = s_epi[row];
             sc2[r] = twoOut ? s_epi[BM + row] : 0.0f; sf2[r] = twoOut ? s_epi[2 * BM + row] : 0.0f;
+            if (!STEMSTACK && act32) { sc2[r] = s_ibn[row]; sf2[r] = s_ibn[SRT_ENC_MAX_CIN + row]; }
             if (STEMSTACK && (r & 7) == 0) stg[r >> 3] = st;            // registers 0..7 are one stem's channels, 8..15 the next stem's (Cout == 16)
             ob[r] = st * p.out_stem + (size_t)co * ohw;
         }
@@ -391,7 +405,11 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
                 const int m = m0 + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (pix_ok && m < mlimit) {
                     if (SPLITK) p.ws[(size_t)bc.ks * p.ws_slice + ob[r] + pbase] = acc[mr][nr][r];      // partial sum; bias is added by the reduce
-                    else p.outRaw[ob[r] + pbase] = acc[mr][nr][r] + bi[r];
+                    else {
+                        const float v = acc[mr][nr][r] + bi[r];
+                        p.outRaw[ob[r] + pbase] = v;
+                        if (!STEMSTACK && act32) p.outAct[ob[r] + pbase] = srt_enc_epilogue(v, sc2[r], sf2[r], ap32);
+                    }
                 }
             }
         }

@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
     constexpr int NIT = 2 * NI * PH * RW4, NLD = (NIT + 255) / 256;
     constexpr int WSLAB = 25 * 512;                         // halves per weight slab (25 KiB)
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[NSPLIT * 2 * PLANE + 2 * WSLAB];
+    __shared__ float s_epi[96];                           // bias | BN scale | BN shift of the workgroup's 32 channels: staged before the K loop (a global load in the epilogue costs its full latency once per workgroup)
     _Float16* s_in = s_mem;
     _Float16* s_w = s_mem + NSPLIT * 2 * PLANE;
 
@@ -86,6 +87,10 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
     const size_t hw = (size_t)p.H * p.W;
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;          // halves per 16-channel group
+    if (tid < BM) {                                         // (visible after the first barrier of the K loop)
+        const size_t ci = stem * p.coeff_stem + min(m0 + tid, p.Cout - 1);
+        s_epi[tid] = p.bias[ci]; s_epi[32 + tid] = p.bnScale[ci]; s_epi[64 + tid] = p.bnShift[ci];
+    }
 
     float4 pin[A16 ? 1 : NLD][8];
     h4 pinh[A16 ? NLD : 1][8];
@@ -204,16 +209,13 @@ __global__ void __launch_bounds__(256, 2) srt_dec_f16(const SrtConvParams p)
         __syncthreads();
     }
 
-    const float* bias = p.bias + stem * p.coeff_stem;
-    const float* scale = p.bnScale + stem * p.coeff_stem;
-    const float* shift = p.bnShift + stem * p.coeff_stem;
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
     float bi[16], sc[16], sf[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * g, p.Cout - 1);
-        bi[r] = bias[m]; sc[r] = scale[m]; sf[r] = shift[m];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        bi[r] = s_epi[row]; sc[r] = s_epi[32 + row]; sf[r] = s_epi[64 + row];
     }
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {

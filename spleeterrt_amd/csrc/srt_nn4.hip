@@ -1248,11 +1248,21 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
 }
 
 // Encoder layers in Winograd form (srt_enc_wino32): the input must be the producer's act(BN(raw)) copy.  Returns 1 when the layer is not covered.
-// Which layers: down4..down6 (Cin >= 64: at least 16 K steps per unit; the short-K layers before them would be all epilogue).
+// Which layers: down3..down6 (Cin >= 32: at least 8 K steps per unit, the continuous stream looks D + 1 = 3 steps ahead).  down3 pays since the
+// direct layer in front writes the act(BN(.)) copy itself (srt_enc_mfma2's second output) and the epilogue no longer loads its constants between
+// its stores: down2 + down3 1.87 -> 1.76 ms.  down2 (Cin = 16, 4 K steps) would be all epilogue, and down1 would have to write a 1 GB copy.
 // SRT_TUNE=encwino=0 keeps the direct kernels, encwino=<min Cin> moves the threshold (tuning builds).
+int srt_enc_producer_copy()
+{
+#ifdef SRT_TUNING
+    const int v = wino_tune("enccopy=");
+    if (v >= 0) return v;
+#endif
+    return 1;
+}
 int srt_enc_wino_covers(int Cin, int Cout, int H, int W)
 {
-    int min_cin = 64;
+    int min_cin = 32;
 #ifdef SRT_TUNING
     const int v = wino_tune("encwino=");
     if (v == 0) return 0;
