@@ -592,6 +592,76 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 }
 
 
+// The same stencil with NRO output rows per thread: output rows h0, h0 + 2, ... (one parity) read the input rows h0 - 3, h0 - 1, ... of the
+// other parity, so NRO of them share all but three of their input rows: 3 (NRO + 3) float4 loads per NRO output quads instead of 12 NRO - for
+// NRO = 4, 5.25 instead of 12 per quad.  The layer is 0.8 GB of HBM traffic; what it was short of is load issue, not bytes.  Per output the taps
+// accumulate in the order of the kernel above (ky, then kx): identical results.
+template <bool LUT, int NRO>
+__global__ void __launch_bounds__(256) srt_head_rows_kernel(const SrtHeadParams p)
+{
+    const int W4 = p.W >> 2, nsets = 2 * ((p.H + 2 * NRO - 1) / (2 * NRO));
+    const int nbx = gridDim.x / (p.nstems * p.ntiles);
+    const int pos = srt_xcd_order(gridDim.x), bx = pos % nbx, inst = pos / nbx;
+    const int stem = inst / p.ntiles, tile = inst % p.ntiles;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* x = p.src + stem * p.src_stem + tile * p.src_tile;
+    float* y = p.out + stem * p.out_stem + tile * p.out_tile;
+    srt_v2f wk[16];                                                          // (channel 0, channel 1) weight of each tap
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { wk[i].x = p.w[stem * p.coeff_stem + i]; wk[i].y = p.w[stem * p.coeff_stem + 16 + i]; }
+    const float b0 = p.bias[stem * p.coeff_stem], b1 = p.bias[stem * p.coeff_stem + 1];
+    const size_t nq = (size_t)nsets * W4;
+    for (size_t e = (size_t)bx * blockDim.x + threadIdx.x; e < nq; e += (size_t)nbx * blockDim.x) {
+        const int w0 = (int)(e % W4) * 4, rs = (int)(e / W4), h0 = (rs & 1) + 2 * NRO * (rs >> 1);
+        srt_v2f a[NRO][4];
+#pragma unroll
+        for (int j = 0; j < NRO; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[j][i].x = 0.f; a[j][i].y = 0.f; }
+#pragma unroll
+        for (int m = 0; m < NRO + 3; ++m) {                                  // input row h0 - 3 + 2 m = row of tap ky = m - j for output row h0 + 2 j
+            const int r = h0 - 3 + 2 * m;
+            const bool rok = r >= 0 && r < p.H;
+            float win[12];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = w0 - 4 + 4 * j;
+                const bool ok = rok && c >= 0 && c < p.W;
+                const float4 v = *reinterpret_cast<const float4*>(x + (ok ? (size_t)r * p.W + c : 0));
+                win[4 * j + 0] = ok ? v.x : 0.f; win[4 * j + 1] = ok ? v.y : 0.f; win[4 * j + 2] = ok ? v.z : 0.f; win[4 * j + 3] = ok ? v.w : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NRO; ++j) {
+                const int ky = m - j;
+                if (ky < 0 || ky > 3) continue;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = win[i + 2 * kx + 1];                 // column w0 + i + 2kx - 3
+                        const srt_v2f vv = { v, v };
+                        a[j][i] = __builtin_elementwise_fma(wk[ky * 4 + kx], vv, a[j][i]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NRO; ++j) {
+            const int h = h0 + 2 * j;
+            if (h >= p.H) continue;
+            float4 o0, o1;
+            if (LUT) {
+                o0.x = srt_sigmoid(a[j][0].x + b0, 0); o0.y = srt_sigmoid(a[j][1].x + b0, 0); o0.z = srt_sigmoid(a[j][2].x + b0, 0); o0.w = srt_sigmoid(a[j][3].x + b0, 0);
+                o1.x = srt_sigmoid(a[j][0].y + b1, 0); o1.y = srt_sigmoid(a[j][1].y + b1, 0); o1.z = srt_sigmoid(a[j][2].y + b1, 0); o1.w = srt_sigmoid(a[j][3].y + b1, 0);
+            } else {
+                o0.x = srt_sigmoid_fast(a[j][0].x + b0); o0.y = srt_sigmoid_fast(a[j][1].x + b0); o0.z = srt_sigmoid_fast(a[j][2].x + b0); o0.w = srt_sigmoid_fast(a[j][3].x + b0);
+                o1.x = srt_sigmoid_fast(a[j][0].y + b1); o1.y = srt_sigmoid_fast(a[j][1].y + b1); o1.z = srt_sigmoid_fast(a[j][2].y + b1); o1.w = srt_sigmoid_fast(a[j][3].y + b1);
+            }
+            *reinterpret_cast<float4*>(y + (size_t)h * p.W + w0) = o0;
+            *reinterpret_cast<float4*>(y + hw + (size_t)h * p.W + w0) = o1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- up6 (Cout = 1)
 // A 1-channel transposed conv has no M dimension for the parity-class form, so this layer uses the GEMM form
 // on the matrix cores: col[tap][pix] = sum_ci w[ci][tap] * x[ci][pix]  (M = 25 taps padded to 32, K = Cin, N = pixels
@@ -942,6 +1012,22 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 
 int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
 {
+#ifndef SRT_HEAD_ROWS_DEFAULT
+#define SRT_HEAD_ROWS_DEFAULT 4
+#endif
+    int nro = SRT_HEAD_ROWS_DEFAULT;
+#ifdef SRT_TUNING
+    if (const char* tv = getenv("SRT_TUNE_HEADROWS")) nro = atoi(tv);         // 0: one output row per thread (srt_head_kernel4), 2, 4
+#endif
+    if (p.W % 4 == 0 && (nro == 2 || nro == 4) && (size_t)p.H * (p.W / 4) * p.nstems * p.ntiles >= (size_t)256 * 1024 * nro) {   // at least 1024 workgroups: four per CU
+        const size_t nsets = 2 * (size_t)((p.H + 2 * nro - 1) / (2 * nro));
+        size_t bx = (nsets * (p.W / 4) + 255) / 256;
+        if (bx > 65535) bx = 65535;
+        const unsigned grid = (unsigned)bx * p.nstems * p.ntiles;
+        if (nro == 4) { if (p.variant == 0) SRT_LAUNCH((srt_head_rows_kernel<true, 4>), dim3(grid), dim3(256), 0, s, p); else SRT_LAUNCH((srt_head_rows_kernel<false, 4>), dim3(grid), dim3(256), 0, s, p); }
+        else { if (p.variant == 0) SRT_LAUNCH((srt_head_rows_kernel<true, 2>), dim3(grid), dim3(256), 0, s, p); else SRT_LAUNCH((srt_head_rows_kernel<false, 2>), dim3(grid), dim3(256), 0, s, p); }
+        return srt_launch_status();
+    }
     if (p.W % 4 == 0) {
         size_t bx4 = ((size_t)p.H * (p.W / 4) + 255) / 256;
 #ifdef SRT_TUNING

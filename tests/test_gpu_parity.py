@@ -188,6 +188,7 @@ def test_up6_streamed_form(oracle, coeffs, T, F, ntiles, stems):
             worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, "up6 stream T=%d F=%d" % (T, F)))
     ks = _layer_kernels(eng, xd)
     assert ks["up6"].startswith("srt_up6_stream_kernel"), ks["up6"]
+    assert ks["up7"].startswith("srt_head_rows_kernel"), ks["up7"]      # the head with four output rows per thread (batches of >= 1024 of its workgroups)
     eng.close()
     print("up6 streamed %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
 
@@ -205,6 +206,27 @@ def test_forward_lut_variant(oracle, coeffs):
         d = np.abs(masks[0, t] - y)
         assert d.max() <= MASK_TOL_LUT
         assert np.mean(d > MASK_TOL_EXACT) < 1e-3        # only points straddling the LUT's +-7 clip may exceed the tight bound
+    eng.close()
+
+
+def test_forward_lut_variant_large_batch(oracle, coeffs):
+    """the LUT-sigmoid flavour (Executable) of the head's large-batch kernel (srt_head_rows_kernel<true, 4>): 140 instances of 64 x 512"""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, ntiles = 64, 512, 35
+    eng = _engine(F=F, T=T, stem_modes=(1, 0, 1, 0), variant=srt.VARIANT_EXE, max_tiles=ntiles)
+    for s in range(4):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=77)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    for s, t in ((0, 0), (1, 17), (3, 34)):
+        y = oracle.forward(coeffs(s), x[t], (1, 0, 1, 0)[s], oracle.VARIANT_EXE)
+        d = np.abs(masks[s, t] - y)
+        assert d.max() <= MASK_TOL_LUT, (s, t, d.max())
+        assert np.mean(d > MASK_TOL_EXACT) < 1e-3
+    ks = _layer_kernels(eng, xd)
+    assert ks["up7"].startswith("srt_head_rows_kernel<true"), ks["up7"]
     eng.close()
 
 
