@@ -240,7 +240,7 @@ def main():
             per.setdefault(name, []).append(ms)
         avg = {k: float(np.mean(v)) for k, v in per.items()}
         inst = STEMS * a.tiles
-        nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP or k == "actcopy")      # actcopy: the bn+act pass in front of the first Winograd-form encoder layer
+        nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP or k == "actcopy")      # actcopy: the fallback bn+act pass in front of the first Winograd-form encoder layer (normally its producer writes the copy)
         nn_flop = FLOP_PER_PIXEL * T * F * inst
         # dominant kernel = the kernel SYMBOL with the largest share of the step (what tops rocprofv3 --stats);
         # achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the engine's stream)

@@ -107,7 +107,7 @@ struct srt_engine {
     float* wpack2_d1;                                  // down1 stem-stacked [2][25][CP2], repacked per launch group (tiny)
     float* wpack2_u5;                                  // up5 class-stacked [n_stems][64][15][32]
     float* wino_u[6]; size_t wino_u_stem[6];           // Winograd-transformed decoder weights (srt_nn4.hip), layers in srt_wino_mask() only
-    float* wino_e[6]; size_t wino_e_stem[6];           // the same for the encoder layers that can run in Winograd form (down4..down6)
+    float* wino_e[6]; size_t wino_e_stem[6];           // the same for the encoder layers that can run in Winograd form (down3..down6)
     float* act32[6];                                   // fp32 act(BN(raw_i)) copies, i = 2..4: the inputs of those layers (written by their producers)
     bool   have_coeff[SRT_MAX_STEMS];
     float* raw[6]; float* up[6];
@@ -464,8 +464,9 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
                 if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
             }
-            // Winograd form (down4..down6 of launches above 16 instances): reads the act(BN(raw)) copy of its input, writes raw + its own copy when
-            // the next layer runs here too.  The first such layer's input copy comes from a batched bn+act pass over the direct producer's raw tensor.
+            // Winograd form (down3..down6 of launches above 16 instances): reads the act(BN(raw)) copy of its input, writes raw + its own copy when
+            // the next layer runs here too.  The first such layer's input copy is written by the direct layer in front (below); only when that layer
+            // ran on a kernel without the second output does a batched bn+act pass over its raw tensor make the copy here.
             const bool ewino = !few && e->wino_e[i] && !e->act16;
             if (ewino) {
                 if (!act_ready) {
