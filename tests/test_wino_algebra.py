@@ -119,3 +119,66 @@ def test_strided_conv_equals_winograd_over_parity_planes():
         y, npts = enc_winograd(x, w)
         assert npts == 49
         assert np.abs(y - enc_direct(x, w)).max() < 1e-12
+
+
+def _wino_unit_xy(sp, tilesX, tilesY, tpw, walk=True):
+    """csrc/srt_nn4.hip wino_sp_xy + the kernels' choice of `colrun`: which spatial tile the unit `sp` of an instance is"""
+    colrun = 1 if not walk else (tpw if tilesY % tpw == 0 else (tilesY if tpw % tilesY == 0 else 1))
+    if colrun > 1:
+        run, step = divmod(sp, colrun)
+        return run % tilesX, (run // tilesX) * colrun + step
+    return sp % tilesX, sp // tilesX
+
+
+def test_column_walk_of_the_winograd_units_is_a_bijection():
+    """The Winograd kernels hand a workgroup `tpw` consecutive units; with the column walk they are tiles of one tile column (so that x neighbours
+    are read by neighbouring workgroups at the same time).  Whatever the geometry, every spatial tile must be visited exactly once, the units
+    of a workgroup must stay inside one instance, and with the walk on they must form a vertical run."""
+    for tilesX in range(1, 10):
+        for tilesY in range(1, 18):
+            nsp = tilesX * tilesY
+            for tpw in (1, 2, 4, 8):
+                if nsp % tpw:                                   # the launcher only picks a tpw that divides the units of an instance group
+                    continue
+                seen = {_wino_unit_xy(sp, tilesX, tilesY, tpw) for sp in range(nsp)}
+                assert seen == {(x, y) for x in range(tilesX) for y in range(tilesY)}, (tilesX, tilesY, tpw)
+                if tilesY % tpw == 0 and tpw > 1:
+                    for wg in range(nsp // tpw):
+                        cells = [_wino_unit_xy(wg * tpw + i, tilesX, tilesY, tpw) for i in range(tpw)]
+                        assert len({x for x, _ in cells}) == 1 and [y for _, y in cells] == list(range(cells[0][1], cells[0][1] + tpw)), (tilesX, tilesY, tpw, cells)
+                        if wg + 1 < nsp // tpw and (wg + 1) % tilesX:      # the next workgroup walks the column to the right, same rows
+                            nxt = _wino_unit_xy((wg + 1) * tpw, tilesX, tilesY, tpw)
+                            assert nxt == (cells[0][0] + 1, cells[0][1]), (tilesX, tilesY, tpw)
+
+
+def test_up6_stream_ring_schedule():
+    """csrc/srt_nn.hip srt_up6_stream_kernel: in interval i the MFMA waves write the tap rows of chunk i (image rows CR i ..) into a ring of 2 CR + 2
+    rows while the gather waves read the rows g - 1 .. g + 1 of the input rows g = CR (i - 1) - 1 + a0 - with ONE barrier per interval.  Replays the
+    schedule on row numbers: what the gather reads must be the right rows, written in EARLIER intervals, and never a slot this interval's MFMA writes."""
+    CR, RR = 2, 6
+    for H in (2, 4, 6, 32, 33, 64, 130):
+        nchunks = (H + CR - 1) // CR + 1
+        ring = [None] * RR                                   # None = zero-initialised, i.e. "a row outside the image"
+        slot0 = 0
+        emitted = []
+        for i in range(nchunks + 1):
+            writes = {}
+            if i < nchunks:
+                for row in range(CR):
+                    writes[(slot0 + row) % RR] = CR * i + row
+            for a0 in range(CR):
+                g = CR * (i - 1) - 1 + a0
+                if 0 <= g < H:
+                    sm = (slot0 - CR - 2 + a0) % RR
+                    for d, want in zip((sm, (sm + 1) % RR, (sm + 2) % RR), (g - 1, g, g + 1)):
+                        assert d not in writes, (H, i, g)
+                        have = ring[d]
+                        if want < 0:
+                            assert have is None, (H, i, g, have)      # above the image: the zero-initialised slot, not yet reused
+                        else:
+                            assert have == want, (H, i, g, have, want)   # (rows >= H were written too: chunks of zeros from the DMA's range check)
+                    emitted.append(g)
+            for s, r in writes.items():
+                ring[s] = r
+            slot0 = (slot0 + CR) % RR
+        assert emitted == list(range(H)), (H, emitted[:8])
