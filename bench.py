@@ -26,6 +26,7 @@ F, T, STEMS, TILES = 1024, 256, 4, 64
 FS, HOP = 44100.0, 1024
 FLOP_PER_PIXEL = 23264                      # per T-F pixel per sub-net, SURVEY §8d (sum of 2MNK over the 13 GEMMs)
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (v_mfma_f32_32x32x16_f16); the 2:1-sparsity figure is never used
 PEAK_HBM_TBS = 8.0
 # FLOP per launch and per instance (one tile of one stem) for every layer kernel, T=256 F=1024
 LAYER_FLOP = {}
@@ -55,12 +56,48 @@ def same_kernel(a, b):
     return ba == bb and aa[:n] == ab[:n]
 
 
-def executed_fraction(symbol):
-    return WINO_EXECUTED_FRACTION if "wino" in symbol else 1.0
+def is_f16_kernel(symbol):
+    """kernels of csrc/srt_nn3.hip (v_mfma_f32_32x32x16_f16), and up6 when its inputs are halves (4th template argument)"""
+    return "_f16<" in symbol or (symbol.startswith("srt_up6_kernel<") and symbol.split("<")[1].split(",")[3].strip().startswith("true"))
 
 
-# written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")]
+def executed_fraction(symbol, precision="f32"):
+    """MFMA products the kernel executes / products of the layer's algorithm (the reference's direct convolution)"""
+    if "wino" in symbol:
+        return WINO_EXECUTED_FRACTION
+    if precision == "f16x2" and "_f16<" in symbol:
+        return 2.0                          # activations split hi + lo: two MFMAs per tap
+    return 1.0
+
+
+def mfma_peak(symbol):
+    return PEAK_F16_MFMA_TFLOPS if is_f16_kernel(symbol) else PEAK_F32_MFMA_TFLOPS
+
+
+def layer_bytes(name, precision, act16):
+    """ALGORITHMIC HBM bytes of one layer per instance (tile x stem): its input(s) read once, its output(s) written once, at the element size
+    the tensors have in this mode (fp16 storage: raw_i, act_i and up_1..5 are halves; the encoder writes raw AND the act(BN(.)) copy).  Weights
+    are read once per launch, not per instance, and are left out (<= 13 MB against GBs)."""
+    e = 2 if act16 else 4
+    if name.startswith("down"):
+        i = int(name[4:]) - 1
+        ci, co = _enc[i]
+        hin, hout = (T >> i) * (F >> i), (T >> (i + 1)) * (F >> (i + 1))
+        rd = ci * hin * (4 if i == 0 else e) / (STEMS if i == 0 else 1)          # the magnitudes are shared by the stems
+        wr = co * hout * e * (2 if (act16 and i < 5) else 1)                      # fp16 storage: raw + act copy
+        return rd + wr
+    if name.startswith("up") and name != "up7":
+        i = int(name[2:]) - 1
+        ci, co = _dec[i]
+        hin = (T >> (6 - i)) * (F >> (6 - i))
+        return ci * hin * e + co * 4 * hin * (4 if i == 5 else e)                 # up6's output (the head's input) stays fp32
+    return T * F * 4 + 2 * T * F * 4                                              # head: one plane in, two masks out
+
+
+# written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first); per precision
+PMC_SUMMARIES = {"f32": [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")],
+                 "f16": [os.path.join(ROOT, "profiles", f) for f in ("r04_f16_pmc.json", "r02_f16_pmc.json")],
+                 "f16x2": [os.path.join(ROOT, "profiles", f) for f in ("r04_f16x2_pmc.json",)]}
 N_SIMD = 1024                               # 256 CUs x 4 SIMDs: SQ_VALU_MFMA_BUSY_CYCLES is summed over them
 
 
@@ -255,15 +292,23 @@ def main():
                 sym_flop[sy] = sym_flop.get(sy, 0.0) + LAYER_FLOP[k] * inst
                 sym_n[sy] = sym_n.get(sy, 0) + 1
         # FLOPs the matrix pipe EXECUTES in one step: the Winograd-form layers issue 0.49 of their algorithmic products
-        nn_exec_flop = sum(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k)) for k in avg if k in LAYER_FLOP)
+        prec = a.precision
+        act16 = prec == "f16" and F % 256 == 0                # fp16 activation storage (csrc/srt_engine.hip: act16)
+        nn_exec_flop = sum(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) for k in avg if k in LAYER_FLOP)
+        # the step's MFMA time budget: every layer's executed FLOPs at the peak of the MFMA it runs on (fp16 modes mix both pipes)
+        nn_peak_ms = sum(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) / (mfma_peak(layer_kernel.get(k, k)) * 1e12) * 1e3 for k in avg if k in LAYER_FLOP)
         dom = max(sym_ms, key=lambda k: sym_ms[k])
         dom_ms = sym_ms[dom] / sym_n[dom]
         dom_flop = sym_flop[dom] / sym_n[dom]
         dom_alg_tflops = dom_flop / (dom_ms * 1e-3) / 1e12    # algorithmic (the reference's direct convolution)
-        dom_exec = executed_fraction(dom)
+        dom_exec = executed_fraction(dom, prec)
         dom_tflops = dom_alg_tflops * dom_exec                # what the matrix pipe executes: the roofline figure
+        dom_peak = mfma_peak(dom)
+        dom_layers = sorted(k for k in avg if layer_kernel.get(k) == dom)
+        dom_bytes = sum(layer_bytes(k, prec, act16) for k in dom_layers) * inst / len(dom_layers)      # algorithmic HBM bytes per launch
+        dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = mfma_busy = pmc_file = None
-        for pf in PMC_SUMMARIES:
+        for pf in PMC_SUMMARIES[prec]:
             try:
                 allpm = json.load(open(pf))
                 pm = allpm.get(dom) or next((v for k, v in allpm.items() if same_kernel(k, dom)), None)
@@ -286,15 +331,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 products, f32 accumulate (conv only; STFT/iSTFT f32)", "f16x2": "f16x2 split products (exact in f32), f32 accumulate"}[a.precision],
             "data": "synthetic",
-            "config": {"workload": "4-stem, fp32, batch=%d spectrogram tiles of %dx%d per GPU (BASELINE configs[2]); "
-                                   "%d frames = %.1f s of audio per GPU per step" % (a.tiles, T, F, frames_step, frames_step * HOP / FS),
+            "config": {"workload": "4-stem, %s, batch=%d spectrogram tiles of %dx%d per GPU (BASELINE configs[2]); "
+                                   "%d frames = %.1f s of audio per GPU per step" % ({"f32": "fp32", "f16": "fp16-MFMA conv + fp32 STFT/iSTFT", "f16x2": "fp16 hi+lo MFMA conv + fp32 STFT/iSTFT"}[a.precision],
+                                                                                     a.tiles, T, F, frames_step, frames_step * HOP / FS),
                        "stems": STEMS, "tiles_per_gpu": a.tiles, "T": T, "F": F, "parallelism": "tile-sharded x%d, no data-path collective" % world,
                        "impl": a.impl, "precision": a.precision},
             "distributed": ({"backend": dist.get_backend() + " (RCCL)", "world": dist.get_world_size(),
                              "collectives": "%d weight-blob broadcasts at start-up; barrier + max-all-reduce around the timed region" % STEMS}
                             if dist_on else None),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": dom_peak, "unit": "TFLOP/s",
+                         "frac": dom_tflops / dom_peak, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, %s)" % pmc_file,
                          "hbm_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "mfma_busy_frac": mfma_busy,
@@ -305,14 +351,20 @@ def main():
                          "note": "achieved / frac / flop_per_launch count the MFMA products the kernel EXECUTES; for a Winograd-form kernel that is 0.49 of the "
                                  "layer's algorithmic FLOPs (algorithmic_* below), so frac cannot exceed 1",
                          "algorithmic_flop_per_launch": dom_flop, "algorithmic_tflops": dom_alg_tflops, "algorithmic_speedup": 1.0 / dom_exec,
+                         # SURVEY 8(d)'s reading (algorithmic FLOPs of the layer / time / peak): above 1 for a Winograd-form kernel, which is why `frac` is on the executed FLOPs
+                         "algorithmic_frac": dom_alg_tflops / dom_peak,
+                         # the same kernel against the HBM roofline: ALGORITHMIC bytes per launch (inputs read once + outputs written once at this mode's element sizes) / time
+                         "hbm": {"achieved": dom_gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": dom_gbs / (PEAK_HBM_TBS * 1e3), "algorithmic_bytes_per_launch": dom_bytes,
+                                 "counter_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None},
                          "share_of_step": sym_ms[dom] / (dt_ev / a.steps * 1e3),
                          # the whole path against the MFMA roofline: algorithmic network FLOP of one step / wall time of one step
-                         "step": {"achieved": nn_exec_flop / (step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": nn_exec_flop / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "step": {"achieved": nn_exec_flop / (step_ms * 1e-3) / 1e12, "peak": nn_exec_flop / (nn_peak_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                  "frac": nn_peak_ms / step_ms,
+                                  "peak_note": "executed FLOPs of the 13 layers / the time they would take at the dense peak of the MFMA each runs on (157.3 fp32, 2500 fp16)",
                                   "algorithmic_tflops": nn_flop / (step_ms * 1e-3) / 1e12, "algorithmic_speedup": nn_flop / nn_exec_flop,
                                   "note": "MFMA FLOPs executed by the 13 layers of one step / ms_per_step (STFT, iSTFT and launch gaps included in the time); "
                                           "algorithmic = 23 264 FLOP per T-F pixel per sub-net x pixels of the step (the reference's direct convolutions)"}},
-            "nn_stack": {"achieved_tflops": nn_exec_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_exec_flop / (nn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "nn_stack": {"achieved_tflops": nn_exec_flop / (nn_ms * 1e-3) / 1e12, "frac": nn_peak_ms / nn_ms,
                          "algorithmic_tflops": nn_flop / (nn_ms * 1e-3) / 1e12, "algorithmic_speedup": nn_flop / nn_exec_flop,
                          "ms": nn_ms, "executed_flop": nn_exec_flop, "algorithmic_flop": nn_flop},
             # the HBM-bound stages against the same guide's 8 TB/s: algorithmic bytes per frame / measured kernel time
@@ -322,9 +374,24 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
             "layer_kernels": {k: layer_kernel[k] for k in sorted(layer_kernel)},
             "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},     # algorithmic
-            "layer_executed_frac": {k: round(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k)) / (avg[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            "layer_executed_frac": {k: round(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) / (avg[k] * 1e-3) / 1e12 / mfma_peak(layer_kernel.get(k, k)), 4)
                                     for k in avg if k in LAYER_FLOP},
+            # every layer against the HBM roofline too (algorithmic bytes at this mode's element sizes / kernel time / 8 TB/s)
+            "layer_hbm_frac": {k: round(layer_bytes(k, prec, act16) * inst / (avg[k] * 1e-3) / (PEAK_HBM_TBS * 1e12), 4) for k in avg if k in LAYER_FLOP},
         }
+        rf = res["roofline"]
+        if rf["hbm"]["frac"] > rf["frac"]:
+            # the dominant kernel is nearer the HBM roofline than the MFMA one (the fp16-MFMA mode is HBM-bound): report THAT as the
+            # bound, with achieved = algorithmic bytes per launch / average launch duration; the MFMA view stays under "mfma"
+            rf["mfma"] = {k: rf[k] for k in ("achieved", "peak", "unit", "frac")}
+            rf.update(bound="hbm", achieved=rf["hbm"]["achieved"], peak=rf["hbm"]["peak"], unit="GB/s", frac=rf["hbm"]["frac"])
+        # the whole step against the HBM roofline: algorithmic bytes of every stage / ms_per_step
+        step_bytes = sum(layer_bytes(k, prec, act16) for k in avg if k in LAYER_FLOP) * inst + (48.8 + 32.8 + STEMS * 16.0) * 1024.0 * rows
+        rf["step"]["hbm"] = {"achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": step_bytes / (step_ms * 1e-3) / (PEAK_HBM_TBS * 1e12),
+                             "algorithmic_bytes": step_bytes}
+        for where, v in (("roofline", rf["frac"]), ("roofline.hbm", rf["hbm"]["frac"]), ("step", rf["step"]["frac"]), ("step.hbm", rf["step"]["hbm"]["frac"]), ("nn_stack", res["nn_stack"]["frac"])):
+            assert 0.0 < v <= 1.0, "roofline fraction %s = %g outside (0, 1]: wrong peak or wrong work count" % (where, v)
+        assert all(0.0 < v <= 1.0 for v in res["layer_executed_frac"].values()), res["layer_executed_frac"]
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_tiles or None)

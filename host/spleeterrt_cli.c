@@ -5,8 +5,11 @@
  *     spleeterrt_cli spawnNthreads timeStep analyseBinLimit stems audioFile.wav [weights.f16]
  *
  * Mirrors Executable/main.c:
- *   argument order, clamps and messages' meaning        main.c:704-748   (spawnNthreads is accepted and ignored:
- *                                                                          the GPU batches the tiles of the file)
+ *   argument order, clamps and messages' meaning        main.c:704-748
+ *   spawnNthreads = how many workers share the file's tiles (main.c:544-673: one pthread, one network instance and one contiguous
+ *   tile range each).  Here a worker is a GPU: min(spawnNthreads, devices of the node) engines, one host thread each, weights uploaded
+ *   once and broadcast over RCCL, ranges joined at their 3072-sample seams (srtMulti*, include/spleeterrt_amd.h).  One device: the
+ *   single-engine path.  $SPLEETERRT_DEVICES="0,1,1" names the engines' devices explicitly (an index may repeat).
  *   any file length: the reference walks the tiles one at a time (main.c:455-495); here the engine holds at most
  *   $SPLEETERRT_MAX_TILES (default 64) tiles and srtSeparateCliHost walks longer files chunk by chunk
  *   4096-sample pre-shift, 4096*ceil(n/4096)+8192 pad   main.c:762-767
@@ -44,8 +47,9 @@ static size_t read_wav(const char *path, float **pcm, unsigned *channels, unsign
 {
     FILE *f = fopen(path, "rb");
     if (!f) { fprintf(stderr, "cannot open %s\n", path); return 0; }
-    unsigned char h[12];
-    if (fread(h, 1, 12, f) == 12 && (!memcmp(h, "RF64", 4) || !memcmp(h, "BW64", 4))) {
+    unsigned char h[12] = { 0 };
+    if (fread(h, 1, 12, f) != 12) { fprintf(stderr, "%s: not a RIFF/WAVE file (shorter than its header)\n", path); fclose(f); return 0; }
+    if (!memcmp(h, "RF64", 4) || !memcmp(h, "BW64", 4)) {
         fprintf(stderr, "%s: RF64/BW64 (a WAVE file beyond 4 GiB) is not supported: the reference's float32 RIFF outputs could not hold the result; split the input\n", path); fclose(f); return 0;
     }
     if (memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) {
@@ -122,7 +126,8 @@ int main(int argc, char **argv)
         return -2;
     }
     double t0 = now();
-    if (atoi(argv[1]) < 1) printf("spawnNthreads clamp to 1\n");
+    int workers = atoi(argv[1]);
+    if (workers < 1) { workers = 1; printf("spawnNthreads clamp to 1\n"); }
     size_t T = 512, F = 1024;
     const int v1 = atoi(argv[2]), v2 = atoi(argv[3]), stems = atoi(argv[4]) <= 2 ? 2 : 3;
     if (v1 < 64) { T = 64; printf("timeStep clamp to 64\n"); } else T = (size_t)v1;
@@ -161,17 +166,47 @@ int main(int argc, char **argv)
      * HBM at once: ~0.1 GB per tile at 512 x 1024); srtSeparateCliHost then walks the file chunk by chunk, so any length works. */
     const char *mt = getenv("SPLEETERRT_MAX_TILES");
     size_t cap = mt && atoi(mt) > 0 ? (size_t)atoi(mt) : 64, ntiles = (rows + T - 1) / T;
-    cfg.variant = SRT_VARIANT_EXE; cfg.max_tiles = (int)(ntiles < cap ? ntiles : cap); cfg.impl = SRT_IMPL_MFMA; cfg.precision = SRT_PREC_F32;
-    srt_engine *e = 0;
-    if (srtCreate(&cfg, 0, &e)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
-    if (srtSetCoeffFp16Host(e, 0, halfs) || srtSetCoeffFp16Host(e, 1, halfs + nhalf)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
-    free(halfs);
+    /* workers -> devices (main.c:544-575: spawnNthreads tile-range workers) */
+    int devs[64], ndev = 0;
+    const char *dl = getenv("SPLEETERRT_DEVICES");
+    if (dl && *dl) {
+        for (const char *q = dl; *q && ndev < 64; ) { devs[ndev++] = atoi(q); q = strchr(q, ','); if (!q) break; ++q; }
+    } else {
+        const int have = srtDeviceCount();
+        ndev = workers < have ? workers : have;
+        if (ndev < 1) ndev = 1;
+        if (ndev > 64) ndev = 64;
+        if ((size_t)ndev > ntiles) ndev = (int)ntiles;                  /* a worker without a tile would idle */
+        for (int g = 0; g < ndev; ++g) devs[g] = g;
+        if (workers > ndev) printf("spawnNthreads %d: %d device worker(s) used (%d device(s), %zu tile(s))\n", workers, ndev, have, ntiles);
+    }
+    const size_t per = (ntiles + (size_t)ndev - 1) / (size_t)ndev;       /* tiles of the largest range */
+    cfg.variant = SRT_VARIANT_EXE; cfg.max_tiles = (int)(per < cap ? per : cap); cfg.impl = SRT_IMPL_MFMA; cfg.precision = SRT_PREC_F32;
     float *out = (float *)malloc((size_t)stems * 2 * len * sizeof(float));
     if (!out) { fprintf(stderr, "out of host memory (%zu output samples)\n", (size_t)stems * 2 * len); return -1; }
-    t0 = now();
-    if (srtSeparateCliHost(e, inL, inR, finalSize, stems, out)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
-    printf("Inference neural networks on the GPU takes %1.14lf sec (%zu tiles of %zu x %zu in chunks of %d, %d outputs)\n", now() - t0, ntiles, T, F, cfg.max_tiles, stems);
-    srtDestroy(e);
+    if (ndev > 1 || (dl && *dl)) {
+        srt_multi *m = 0;
+        char info[256];
+        if (srtMultiCreate(&cfg, devs, ndev, &m)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        if (srtMultiSetCoeffFp16Host(m, 0, halfs) || srtMultiSetCoeffFp16Host(m, 1, halfs + nhalf)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        free(halfs);
+        t0 = now();
+        if (srtMultiSeparateCliHost(m, inL, inR, finalSize, stems, out)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        srtMultiInfo(m, info, sizeof info);
+        printf("Inference neural networks on %d GPU worker(s) takes %1.14lf sec (%zu tiles of %zu x %zu, at most %zu per worker in chunks of %d, %d outputs; %s)\n",
+               ndev, now() - t0, ntiles, T, F, per, cfg.max_tiles, stems, info);
+        srtMultiDestroy(m);
+    } else {
+        srt_engine *e = 0;
+        if (srtCreate(&cfg, 0, &e)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        if (srtSetCoeffFp16Host(e, 0, halfs) || srtSetCoeffFp16Host(e, 1, halfs + nhalf)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        free(halfs);
+        t0 = now();
+        if (srtSeparateCliHost(e, inL, inR, finalSize, stems, out)) { fprintf(stderr, "%s\n", srtLastError()); return -1; }
+        printf("Inference neural networks on the GPU takes %1.14lf sec (%zu tiles of %zu x %zu in chunks of %d, %d outputs)\n", now() - t0, ntiles, T, F, cfg.max_tiles, stems);
+        srtReleaseStaging(e);                                          /* whole-file device copies of a one-shot program */
+        srtDestroy(e);
+    }
 
     static const char *names2[] = { "Vocal", "Accompaniment" }, *names3[] = { "Drum", "Vocal", "Accompaniment" };
     const char **names = stems == 2 ? names2 : names3;

@@ -52,7 +52,7 @@ typedef struct srt_config {
                                      * m_s^2 / sum_j m_j^2 across stems (README.MD:82-85).  The CLI flows (srtSeparateCli*) reject it: their
                                      * sub-networks run one after the other on different inputs, so there is no stem axis to normalise over. */
     int   batch_invariant;          /* 0 (default): the fastest kernel per launch - small launches (<= 16 instances) cut the deep layers' K loops
-                                     * into slices (split-K) and keep the direct decoder kernels, larger ones run up2..up5 in Winograd form, so the
+                                     * into slices (split-K) and keep the direct kernels, larger ones run up1..up5 and down3..down6 in Winograd form, so the
                                      * same tile can differ in the last bits (<= 2e-5 on masks) with the batch it is evaluated in.
                                      * 1: kernel choice by layer geometry only, no split-K: a tile's result is bit-identical whatever the batch
                                      * size, tile slot, stem range or rank partition (what the reference's CPU path guarantees); small batches
@@ -109,7 +109,9 @@ SRT_API int  srtSeparateHostStreamEx(srt_engine *e, const float *h_L, const floa
  * Sub-network 0 = the CLI's net[0] (drum, stem_mode 1), sub-network 1 = net[1] (vocal, stem_mode 0)  (main.c:759-760).
  * d_out: [stems][2][srtIstftLength(srtStftRows(n))] in the CLI's output order: Vocal, Accompaniment | Drum, Vocal, Accompaniment. */
 SRT_API int  srtSeparateCli(srt_engine *e, const float *d_L, const float *d_R, size_t n, int stems, float *d_out);
-SRT_API int  srtSeparateCliHost(srt_engine *e, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);  /* host buffers, synchronous */
+/* host buffers, synchronous.  Its device staging (whole-file PCM + outputs when the file fits max_tiles, chunk double buffers otherwise) is
+ * grow-only and kept for later calls, like srtSeparateHostStream's; a one-shot caller frees it with srtReleaseStaging. */
+SRT_API int  srtSeparateCliHost(srt_engine *e, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);
 
 /* Low-latency callers that repeat the same call (same device pointers and sizes) over and over - the real-time plugin, the tile
  * API on one pair of buffers: with graph mode on, srtForward and srtSeparate / srtSeparateEx capture their launch sequence into
@@ -124,6 +126,31 @@ SRT_API int  srtSetGraphMode(srt_engine *e, int enable);
 SRT_API int  srtPrepareForward(srt_engine *e, const float *d_mag, int ntiles, float *d_masks);
 /* free the grow-only device staging of the host-buffer entry points (srtSeparateHostStream*, srtSeparateCliHost); the next such call re-allocates */
 SRT_API int  srtReleaseStaging(srt_engine *e);
+
+/* ---- one node, several devices: the reference CLI's tile-range fan-out (Executable/main.c:544-673, `processMT`: spawnNthreads workers, each with
+ * its own network instance and a contiguous tile range, one shared read-only weight blob) with a GPU where the reference has a CPU thread.
+ * One engine per entry of `devices` (an index may repeat: several engines on one GPU), one host thread per engine while a call runs; weights are
+ * uploaded once and distributed with one ncclBroadcast per blob over the devices (RCCL, loaded on first use; hipMemcpyPeer when it is absent or
+ * SPLEETERRT_NO_RCCL=1); no data-path collective - neighbouring ranges share 3072 output samples, which the call adds on the host when it joins. */
+typedef struct srt_span {           /* one rank's share of an n-sample stream; same arithmetic as spleeterrt_amd/stream.py:rank_span */
+    size_t tile0, tile1;            /* tiles [tile0, tile1) */
+    size_t sample0, nsamples;       /* PCM samples [sample0, sample0 + nsamples): the range + its 3072-sample halo */
+    size_t frames, rows;            /* frames that receive a transform / spectrogram rows of the range (srtSeparateEx geometry) */
+    size_t out_offset;              /* where the range's overlap-add contribution (rows*1024 + 3072 samples) starts in the output */
+} srt_span;
+typedef struct srt_multi srt_multi;
+SRT_API int  srtDeviceCount(void);                                               /* HIP devices visible to the process (0: none) */
+SRT_API int  srtRankSpan(size_t n, int T, int rank, int world, srt_span *out);   /* pure host arithmetic: works without a device */
+SRT_API int  srtMultiCreate(const srt_config *cfg, const int *devices /* NULL: 0..ndev-1 */, int ndev, srt_multi **out);  /* cfg->max_tiles: per engine */
+SRT_API void srtMultiDestroy(srt_multi *m);
+SRT_API int  srtMultiSetCoeffHost(srt_multi *m, int stem, const void *h_coeff);              /* spleeterCoeff, fp32 */
+SRT_API int  srtMultiSetCoeffFp16Host(srt_multi *m, int stem, const uint16_t *h_halfs);      /* spleeterQuantizedSubNet */
+/* whole host-resident stream, the engine's n_stems sub-networks: h_out [n_stems][2][srtIstftLength(srtStftRows(n))]; flags as srtSeparateHostStreamEx */
+SRT_API int  srtMultiSeparateHost(srt_multi *m, const float *h_L, const float *h_R, size_t n, float *h_out, unsigned flags);
+/* the offline CLI's flows (srtSeparateCliHost) over the devices: h_out [stems][2][srtIstftLength(srtStftRows(n))] */
+SRT_API int  srtMultiSeparateCliHost(srt_multi *m, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);
+/* "engines=2 devices=0,1 distinct=2 weights=rccl broadcasts=2" (tests, logs); returns the number of engines */
+SRT_API int  srtMultiInfo(const srt_multi *m, char *text, size_t bytes);
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */

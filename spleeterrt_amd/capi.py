@@ -22,6 +22,11 @@ class _Config(C.Structure):
                 ("ratio_mask", C.c_int), ("batch_invariant", C.c_int)]
 
 
+class Span(C.Structure):
+    """srt_span (include/spleeterrt_amd.h): one rank's share of a stream, as srtRankSpan fills it."""
+    _fields_ = [(k, C.c_size_t) for k in ("tile0", "tile1", "sample0", "nsamples", "frames", "rows", "out_offset")]
+
+
 _lib = None
 
 
@@ -66,6 +71,16 @@ def load_library():
     L.srtSetTiming.argtypes = [vp, C.c_int]
     L.srtGetTiming.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
     L.srtGetTimingKernels.argtypes = [vp, C.c_char_p, C.c_size_t]
+    # multi-device host driver (csrc/srt_multi.hip)
+    L.srtRankSpan.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Span)]
+    L.srtMultiCreate.argtypes = [C.POINTER(_Config), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.srtMultiDestroy.argtypes = [vp]
+    L.srtMultiDestroy.restype = None
+    L.srtMultiSetCoeffHost.argtypes = [vp, C.c_int, vp]
+    L.srtMultiSetCoeffFp16Host.argtypes = [vp, C.c_int, vp]
+    L.srtMultiSeparateHost.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint]
+    L.srtMultiSeparateCliHost.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+    L.srtMultiInfo.argtypes = [vp, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 

@@ -452,19 +452,21 @@ int srt_launch_residual(const SrtResidualParams& p, hipStream_t s)
     return srt_launch_status();
 }
 
-__global__ void __launch_bounds__(256) srt_time_residual_kernel(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out)
+// out = a - b on samples [lo, hi) of two planes of nb floats (a: two separate planes of na valid samples, zero beyond)
+__global__ void __launch_bounds__(256) srt_time_residual_kernel(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, size_t lo, size_t hi)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nb) return;
+    const size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hi) return;
     const float* a = blockIdx.y ? aR : aL;
     const size_t o = (size_t)blockIdx.y * nb + i;
     out[o] = (i < na ? a[i] : 0.0f) - b[o];
 }
 
-int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s)
+int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, size_t lo, size_t hi, hipStream_t s)
 {
-    if (!nb) return 0;
-    SRT_LAUNCH(srt_time_residual_kernel, dim3((unsigned)((nb + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out);
+    if (hi > nb) hi = nb;
+    if (hi <= lo) return 0;
+    SRT_LAUNCH(srt_time_residual_kernel, dim3((unsigned)((hi - lo + 255) / 256), 2), dim3(256), 0, s, aL, aR, na, b, nb, out, lo, hi);
     return srt_launch_status();
 }
 

@@ -229,6 +229,9 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     }
     EALLOC(e->wpack2_d1, (size_t)2 * 25 * 128);
     EALLOC(e->wpack2_u5, S * 64 * 15 * 32);
+    // The Winograd-form layers only ever run on launches above 16 instances (forward_range: `few`) or under batch_invariant: an engine that can never
+    // hold that many (every drop-in tile-API / plugin instance: 1 tile x 1-4 stems) does not allocate their transformed weights and input copies.
+    const bool wino_possible = S * NT > 16 || e->cfg.batch_invariant || srt_wino_force();
     for (int i = 0; i < 6; ++i) {
         e->wpack_down_stem[i] = (size_t)e->lo.down[i].cin * 25 * e->lo.down[i].cp;
         e->wpack_up_stem[i] = (size_t)e->lo.up[i].cin * 25 * e->lo.up[i].cp;
@@ -236,12 +239,12 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
         EALLOC(e->wpack_up[i], S * e->wpack_up_stem[i]);
         // Winograd form of the decoder layers named by srt_wino_mask() (fp32 MFMA path): [Cin/4][Cout/16][4][16][52] per stem
         const LayerOff& U = e->lo.up[i];
-        if (cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && ((srt_wino_mask() >> i) & 1) && U.cout % 16 == 0 && U.cin % 4 == 0) {
+        if (wino_possible && cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && ((srt_wino_mask() >> i) & 1) && U.cout % 16 == 0 && U.cin % 4 == 0) {
             e->wino_u_stem[i] = (size_t)U.cin * U.cout * 52;
             EALLOC(e->wino_u[i], S * e->wino_u_stem[i]);
         }
         const LayerOff& Dn = e->lo.down[i];
-        if (cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && i >= 1 && srt_enc_wino_covers(Dn.cin, Dn.cout, cfg->T >> i, cfg->F >> i)) {
+        if (wino_possible && cfg->impl == SRT_IMPL_MFMA && cfg->precision == SRT_PREC_F32 && i >= 1 && srt_enc_wino_covers(Dn.cin, Dn.cout, cfg->T >> i, cfg->F >> i)) {
             e->wino_e_stem[i] = (size_t)Dn.cin * Dn.cout * 52;
             EALLOC(e->wino_e[i], S * e->wino_e_stem[i]);
             EALLOC(e->act32[i - 1], S * NT * ((size_t)ENC_CH[i - 1][1] * (HW >> (2 * i))));        // act(BN(raw_{i-1})): this layer's input
@@ -416,9 +419,9 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (e->stream) (void)hipStreamIsCapturing(e->stream, &cap);
     if (cap == hipStreamCaptureStatusNone) ensure_ws(e, (size_t)ns * ntiles);      // (no allocation inside a capture: callers pre-allocate)
-    // Kernel choice by launch size: at most 16 instances keep the direct decoder kernels and (when the workspace exists) cut the deep
-    // layers' K loops into slices; larger launches run up2..up5 in Winograd form.  batch_invariant: never split-K (ws stays null) and
-    // the Winograd decoders whenever the layer geometry fits, whatever the batch - the same bits for a tile in any batch.
+    // Kernel choice by launch size: at most 16 instances keep the direct kernels and (when the workspace exists) cut the deep layers' K loops
+    // into slices; larger launches run up1..up5 and down3..down6 in Winograd form.  batch_invariant: never split-K (ws stays null) and the
+    // Winograd-form layers whenever the layer geometry fits, whatever the batch - the same bits for a tile in any batch.
     const bool few = (size_t)ns * ntiles <= 16 && !e->cfg.batch_invariant;
     const bool small = few && e->ws;
     {
@@ -727,11 +730,13 @@ static int istft_one(srt_engine* e, const float2* spec, size_t rows, const float
 // Explicit geometry as srtSeparateEx (a tile range of a longer file).  residual_now = false leaves the last, time-domain subtraction
 // to the caller: the chunked pipeline first adds the previous chunk's overlap to every plane (the accompaniment slot then holds
 // the UNsubtracted term: nothing for 2 outputs, istft(R) for 3) and subtracts afterwards (cli_time_residual).
-static int cli_time_residual(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out, size_t len)
+// samples [lo, hi) of the planes (hi = 0: all of them)
+static int cli_time_residual(srt_engine* e, const float* d_L, const float* d_R, size_t n, int stems, float* d_out, size_t len, size_t lo = 0, size_t hi = 0)
 {
     TimerScope ts(e, "residual");
-    const int rc = stems == 2 ? srt_launch_time_residual(d_L, d_R, n, d_out, len, d_out + 2 * len, e->stream)
-                              : srt_launch_time_residual(d_out + 4 * len, d_out + 5 * len, len, d_out + 2 * len, len, d_out + 4 * len, e->stream);
+    if (!hi) hi = len;
+    const int rc = stems == 2 ? srt_launch_time_residual(d_L, d_R, n, d_out, len, d_out + 2 * len, lo, hi, e->stream)
+                              : srt_launch_time_residual(d_out + 4 * len, d_out + 5 * len, len, d_out + 2 * len, len, d_out + 4 * len, lo, hi, e->stream);
     return rc ? fail(-2, "residual launch failed") : 0;
 }
 
@@ -824,7 +829,9 @@ static int ensure_staging(srt_engine* e, size_t in_floats, size_t out_floats, si
     return 0;
 }
 
-static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems);
+// seam: how a tile RANGE of a longer stream joins its neighbours when they run on other devices (srt_multi.hip); {0, nullptr, false} = the whole stream
+struct SrtSeam { size_t out_stride; float* h_tail; bool head; };
+static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems, SrtSeam seam = SrtSeam{0, nullptr, false});
 
 // Host-buffer form of srtSeparateCli for plain-C callers (the CLI harness): synchronous.  A file that fits the engine's capacity
 // (max_tiles tiles) is one resident batch: H2D, chain, D2H.  A longer one - any length, as the reference's tile loop over a
@@ -853,8 +860,7 @@ int srtSeparateCliHost(srt_engine* e, const float* h_L, const float* h_R, size_t
         if (er != hipSuccess) rc = fail(-2, "HIP error: %s", hipGetErrorString(er));
     }
     hipStreamSynchronize(e->stream);
-    free_staging(e);                                           // whole-file device copies of a one-shot call: not kept until srtDestroy
-    return rc;
+    return rc;                                                 // (the staging is grow-only and reused by later calls; srtReleaseStaging frees it)
 }
 
 int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* d_out)
@@ -869,14 +875,19 @@ int srtSeparate(srt_engine* e, const float* d_L, const float* d_R, size_t n, flo
 // sample crosses PCIe exactly once.  Geometry as srtSeparateEx (a tile range of a longer stream: rows = whole tiles,
 // frames = rows; the whole stream: rows = srtStftRows(n), frames = srtStftFrames(n)).
 // cli_stems = 0: the n_stems sub-networks on the same input (srtSeparateEx per chunk); 2 / 3: the CLI's flows (cli_issue per chunk)
-static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems)
+// seam (multi-device ranges, srt_multi.hip): h_out points at the range's first sample inside planes of seam.out_stride floats (the whole
+// stream's output length); with seam.h_tail the range's last 3072 samples - the overlap-add contribution that belongs to the NEXT range's
+// first samples - go to h_tail [planes][3072] instead of h_out; seam.head says a previous range will add its tail to this range's first
+// 3072 samples.  The CLI flows' time-domain subtraction is left out on exactly those seam samples (both contributions have to be added
+// first: the joiner does that, as the reference's main() does its subtraction on the host, main.c:794-798).
+static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags, int cli_stems, SrtSeam seam)
 {
     if (!e || !h_L || !h_R || !h_out) return fail(-1, "srtSeparateHostStream: null argument");
     if (rows < 1 || frames > rows) return fail(-1, "srtSeparateHostStream: need 1 <= frames <= rows");
     DeviceScope ds(e->device);
     const int S = cli_stems ? cli_stems : e->cfg.n_stems, T = e->cfg.T, NP = S * 2;
     const size_t chunk_rows = (size_t)e->cfg.max_tiles * T, tail = SRT_FFT - SRT_HOP;
-    const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows, total_len = srtIstftLength(rows);
+    const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows, total_len = seam.out_stride ? seam.out_stride : srtIstftLength(rows);
     const size_t in_cap = chunk_rows * SRT_HOP + tail, out_cap = srtIstftLength(chunk_rows);
     int rc = ensure_staging(e, 2 * in_cap, (size_t)NP * out_cap, (size_t)NP * tail, 2);
     if (rc) return rc;
@@ -888,7 +899,7 @@ static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t
     if (!(flags & SRT_HOST_PINNED)) {
         pinL = hipHostRegister((void*)h_L, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
         pinR = hipHostRegister((void*)h_R, n * sizeof(float), hipHostRegisterDefault) == hipSuccess;
-        pinO = hipHostRegister((void*)h_out, (size_t)NP * total_len * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+        pinO = !seam.out_stride && hipHostRegister((void*)h_out, (size_t)NP * total_len * sizeof(float), hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
     }
     hipError_t er = hipSuccess;
@@ -916,12 +927,17 @@ static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t
         if (rc) break;
         if (srt_launch_carry(h.d_out[b], clen, NP, crow * SRT_HOP, h.d_carry, c == 0, c + 1 == nchunks, e->stream)) { rc = fail(-2, "carry launch failed"); break; }
         // CLI flows: the time-domain subtraction comes after the seam has been added (the planes now hold the stitched signals)
-        if (cli_stems && (rc = cli_time_residual(e, h.d_in[b], h.d_in[b] + in_cap, ns, cli_stems, h.d_out[b], clen))) break;
+        const bool to_tail = c + 1 == nchunks && seam.h_tail;                      // the range's last 3072 samples belong to the next range's seam
+        if (cli_stems) {
+            const size_t lo = c == 0 && seam.head ? tail : 0, hi = to_tail ? crow * SRT_HOP : clen;
+            if (hi > lo && (rc = cli_time_residual(e, h.d_in[b], h.d_in[b] + in_cap, ns, cli_stems, h.d_out[b], clen, lo, hi))) break;
+        }
         STEP(hipEventRecord(h.ev_cmp[b], e->stream));
         // download: every plane's [0, crow*1024) (+ the final 3072 on the last chunk) lands at its place in h_out
         STEP(hipStreamWaitEvent(h.s_out, h.ev_cmp[b], 0));
-        const size_t take = c + 1 == nchunks ? clen : crow * SRT_HOP;
+        const size_t take = c + 1 == nchunks && !to_tail ? clen : crow * SRT_HOP;
         STEP(hipMemcpy2DAsync(h_out + s0, total_len * sizeof(float), h.d_out[b], clen * sizeof(float), take * sizeof(float), NP, hipMemcpyDeviceToHost, h.s_out));
+        if (to_tail) STEP(hipMemcpy2DAsync(seam.h_tail, tail * sizeof(float), h.d_out[b] + crow * SRT_HOP, clen * sizeof(float), tail * sizeof(float), NP, hipMemcpyDeviceToHost, h.s_out));
         STEP(hipEventRecord(h.ev_out[b], h.s_out));
     }
 #undef STEP
@@ -934,6 +950,16 @@ static int host_stream(srt_engine* e, const float* h_L, const float* h_R, size_t
     if (pinO) hipHostUnregister((void*)h_out);
     return rc;
 }
+
+int srt_engine_host_range(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, size_t out_stride,
+                          float* h_tail, bool head, unsigned flags, int cli_stems)
+{
+    if (cli_stems) { DeviceScope ds(e->device); const int rc = cli_check(e, cli_stems); if (rc) return rc; }
+    return host_stream(e, h_L, h_R, n, frames, rows, h_out, flags, cli_stems, SrtSeam{out_stride, h_tail, head});
+}
+const float* srt_engine_coeff_device(const srt_engine* e, int stem) { return e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE; }
+int srt_engine_device(const srt_engine* e) { return e->device; }
+void* srt_engine_stream(const srt_engine* e) { return (void*)e->stream; }
 
 int srtSeparateHostStreamEx(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, unsigned flags)
 {

@@ -159,8 +159,8 @@ struct SrtResidualParams {
     float* mag;               // [ntiles][2][T][F]
 };
 int srt_launch_residual(const SrtResidualParams& p, hipStream_t s);
-// out[c][i] = (i < na ? a[c][i] : 0) - b[c][i], i < nb, two channels (time-domain residual, main.c:794-798, 924-928)
-int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, hipStream_t s);
+// out[c][i] = (i < na ? a[c][i] : 0) - b[c][i] for lo <= i < min(hi, nb), two channels of plane length nb (time-domain residual, main.c:794-798, 924-928)
+int srt_launch_time_residual(const float* aL, const float* aR, size_t na, const float* b, size_t nb, float* out, size_t lo, size_t hi, hipStream_t s);
 // chunk stitching on the device: out[p][0:3072] += carry[p] (unless first), then carry[p] = out[p][tail : tail+3072] (unless last)
 int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, float* carry, int first, int last, hipStream_t s);
 // cross-stem ratio mask, in place on [nstems][count]: m_s <- (m_s^2 + eps/S) / (sum_j m_j^2 + eps)
@@ -182,3 +182,14 @@ struct SrtStreamHop {
     const float* analysisWnd; const float* synthesisWnd; const float2* twiddle;
 };
 int srt_launch_stream_hop(const SrtStreamHop& p, hipStream_t s);
+
+// ---- multi-device host driver (srt_multi.hip) over the engine (srt_engine.hip)
+struct srt_engine;
+// One tile RANGE of a longer host-resident stream through engine `e` (chunked, copies overlapped with compute): h_out points at the range's first
+// output sample inside planes of out_stride floats; h_tail (may be null: last range) receives the range's last 3072 samples per plane - the overlap-add
+// contribution to the next range's first samples; head: a previous range will add its tail to this range's first 3072 samples.  cli_stems 0 | 2 | 3.
+int srt_engine_host_range(srt_engine* e, const float* h_L, const float* h_R, size_t n, size_t frames, size_t rows, float* h_out, size_t out_stride,
+                          float* h_tail, bool head, unsigned flags, int cli_stems);
+const float* srt_engine_coeff_device(const srt_engine* e, int stem);      // the stem's fp32 spleeterCoeff blob in the engine's HBM (valid after srtSetCoeff*)
+int srt_engine_device(const srt_engine* e);
+void* srt_engine_stream(const srt_engine* e);

@@ -144,8 +144,26 @@ def test_bench_takes_kernel_names_from_the_engine(lib):
         m = re.search(r"(?:void )?(?:__device_stub__)?(srt_\w+(?:<[^(]*>)?)\(", ln)
         if m:
             have.add(m.group(1))
-    newest = next(p for p in bench.PMC_SUMMARIES if os.path.exists(p))
+    newest = next(p for p in bench.PMC_SUMMARIES["f32"] if os.path.exists(p))
     named = [k for k in json.load(open(newest)) if re.match(r"srt_(enc|dec|up6|head)\w*<", k)]
     assert named, newest
     missing = [k for k in named if not any(bench.same_kernel(k, h) for h in have)]
     assert not missing, "%s names kernels the library does not contain (re-run scripts/profile_gpu.sh): %r" % (newest, missing)
+
+
+def test_bench_roofline_peaks_follow_the_precision():
+    """bench.py prices a kernel against the peak of the MFMA it runs on (157.3 TFLOP/s fp32, 2500 dense fp16), counts the two MFMAs per tap
+    of the split mode, and knows the algorithmic bytes of every layer at the mode's element sizes (the HBM roofline of the fp16 path)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.mfma_peak("srt_enc_f16<32, 1, 4, 1, 1, true>") == 2500.0 and bench.mfma_peak("srt_dec_f16<32, 2, 4, 1, 1, true>") == 2500.0
+    assert bench.mfma_peak("srt_up6_kernel<8, 64, 32, true, 2>") == 2500.0 and bench.mfma_peak("srt_up6_kernel<8, 64, 32, false, 2>") == 157.3
+    assert bench.mfma_peak("srt_dec_wino32<2, 16, 0, 3, 2, 1, 1, 0, 1, 1, 1>") == 157.3 and bench.mfma_peak("srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false, false>") == 157.3
+    assert bench.executed_fraction("srt_enc_f16<32, 1, 4, 1, 1, true>", "f16x2") == 2.0 and bench.executed_fraction("srt_enc_f16<32, 1, 4, 1, 1, true>", "f16") == 1.0
+    assert bench.executed_fraction("srt_enc_wino32<2, 16, 1, 0>") == 0.49
+    # bytes: up2 at 256 x 1024 reads 512 channels of 8 x 32 and writes 128 of 16 x 64, fp32 / fp16 storage
+    assert bench.layer_bytes("up2", "f32", False) == 512 * 8 * 32 * 4 + 128 * 16 * 64 * 4
+    assert bench.layer_bytes("up2", "f16", True) == (512 * 8 * 32 + 128 * 16 * 64) * 2
+    assert bench.layer_bytes("down2", "f16", True) == 16 * 128 * 512 * 2 + 32 * 64 * 256 * 2 * 2          # raw + act copy, halves
+    assert bench.layer_bytes("up6", "f16", True) == 32 * 128 * 512 * 2 + 256 * 1024 * 4                    # up6's output stays fp32

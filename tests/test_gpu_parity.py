@@ -704,9 +704,11 @@ def test_ratio_mask(oracle, coeffs):
 
 def test_full_size_batch_properties(oracle, coeffs):
     """BASELINE configs[2] at full size (4 stems x 64 tiles of 256x1024), through size-independent properties:
-    tiles are independent (a tile's masks do not depend on its batch mates or its slot), a T-periodic signal gives
-    identical masks in every tile, masks are finite and inside [0,1], unit masks give back the input (STFT -> iSTFT
-    identity, stftFix.c round trip), and one (tile, stem) of the batch matches the CPU oracle."""
+    a T-periodic signal gives identical masks in every interior tile; tiles are independent - checked on a batch of 64 DISTINCT tiles
+    (seeded noise per tile, so a cross-tile mix-up cannot hide behind identical inputs): permuting the tiles of the batch permutes the
+    masks bit for bit, and a tile's masks do not depend on its batch mates; masks are finite and inside [0,1], unit masks give back the
+    input (STFT -> iSTFT identity, stftFix.c round trip), and one (tile, stem) of the batch matches the CPU oracle.  (Per-tap parity at
+    this launch size: test_shipped_launch_shapes_per_tap.)"""
     import torch
     import spleeterrt_amd as srt
     T, F, S, NT = 256, 1024, 4, 64
@@ -726,6 +728,17 @@ def test_full_size_batch_properties(oracle, coeffs):
     assert torch.equal(mag[5], mag[40])
     for j in (6, 31, 62):
         assert torch.equal(masks[:, 5], masks[:, j]), "tile %d differs from tile 5" % j
+    # independence on DISTINCT tiles: a permutation of the batch permutes the masks, bit for bit (same kernels, same launch size; a tile that
+    # read a neighbour's rows, channels or slot would change with its neighbours)
+    xd = torch.from_numpy(_mag_input(oracle, NT, T, F, seed=9001)).cuda()
+    assert not torch.equal(xd[5], xd[40])
+    m1 = eng.forward(xd).clone()
+    perm = torch.from_numpy(np.random.RandomState(7).permutation(NT)).cuda()
+    m2 = eng.forward(xd[perm].contiguous())
+    assert torch.equal(m2, m1[:, perm]), "masks of a permuted batch are not the permuted masks"
+    xz = xd.clone(); xz[:31] = 0.0; xz[32:] = 0.0                        # tile 31 among silent batch mates
+    assert torch.equal(eng.forward(xz)[:, 31], m1[:, 31])
+    del m1, m2, xz
     # a tile evaluated alone (batch of 1, slot 0) == the same tile inside the 64-tile batch; alone, its deep layers run as
     # split-K launches (small-batch path), so only the association of the K sums differs
     alone = eng.forward(mag[17:18].contiguous())
@@ -744,4 +757,112 @@ def test_full_size_batch_properties(oracle, coeffs):
     out = eng.separate(L, R)
     ref_out = eng.istft(spec, masks)
     assert torch.equal(out, ref_out)
+    eng.close()
+
+
+# ------------------------------------------------------------------ the launch shapes the headline is timed on, per tap
+SHIPPED_KERNELS = {      # bench.py's `layer_kernels` at 64 tiles x 4 stems of 256 x 1024 (profiles/r0x_bench_n1.json); template arguments may move with tuning, the families may not
+    "down1": "srt_enc_mfma2<", "down2": "srt_enc_mfma2<", "down3": "srt_enc_wino32<", "down4": "srt_enc_wino32<", "down5": "srt_enc_wino32<", "down6": "srt_enc_wino32<",
+    "up1": "srt_dec_wino32<", "up2": "srt_dec_wino32<", "up3": "srt_dec_wino32<", "up4": "srt_dec_wino32<", "up5": "srt_dec_wino", "up6": "srt_up6_stream_kernel<", "up7": "srt_head_rows_kernel<",
+}
+
+
+def test_shipped_launch_shapes_per_tap(oracle, coeffs):
+    """BASELINE configs[2] exactly as bench.py launches it - 64 tiles x 4 stems of 256 x 1024, i.e. the grids, units per workgroup, column
+    walks and kernel choices of the headline number - on 64 DISTINCT tiles (seeded noise per tile): every intermediate tensor of the first,
+    an interior and the last tile of stems 0 and 3 against the CPU oracle (rel-RMS and max-abs / peak), the masks of those instances, the
+    kernel families named by the engine, and the stems of two tiles end to end (PCM -> STFT -> masks -> iSTFT) against
+    oracle.stft -> process_spectrogram -> istft."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S, NT = 256, 1024, 4, 64
+    modes, oob = (1, 1, 1, 1), (0.25, 0.0, 0.25, 0.25)
+    eng = _engine(F=F, T=T, stem_modes=modes, oob_weights=oob, variant=srt.VARIANT_VST, max_tiles=NT)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, NT, T, F, seed=64256)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    worst = (0.0, 0.0)
+    for s in (0, 3):
+        for t in (0, 37, NT - 1):
+            worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, "64x4 256x1024"))
+    ks = _layer_kernels(eng, xd)
+    for name, fam in SHIPPED_KERNELS.items():
+        assert ks[name].startswith(fam), (name, ks[name])
+    assert "actcopy" not in ks
+    # end to end on distinct audio: 64 tiles of seeded noise + tones, tiles 0 and 41 of every stem against the oracle chain of their own PCM span
+    n = NT * T * 1024
+    L, R = oracle.synth_audio(n, 20240, True)
+    out = eng.separate(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    for t in (0, 41):
+        s0, s1 = t * T * 1024, (t + 1) * T * 1024 + 3072
+        re, im = oracle.stft(L[s0:s1].copy(), R[s0:s1].copy())
+        re, im = re[:, :T], im[:, :T]                                        # the tile's own rows (the halo frames belong to the next tile)
+        lo, hi = s0 + 3072, s0 + T * 1024                                    # samples that only this tile's frames reach
+        for s in range(S):
+            r, i = re.copy(), im.copy()
+            oracle.process_spectrogram(coeffs(s), r, i, F, T, modes[s], oracle.VARIANT_VST, oob[s])
+            ref = oracle.istft(r, i)[:, 3072:T * 1024]
+            got = out[s][:, lo:hi]
+            assert _rel_rms(got, ref) <= 1e-4, (t, s, _rel_rms(got, ref))
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (t, s)
+    eng.close()
+    print("shipped shapes 64x4 256x1024: worst tap rel-rms %.3g, max-abs/peak %.3g; %s" % (worst[0], worst[1], ks))
+
+
+@pytest.mark.parametrize("T,F,ntiles,stems,taps", [
+    (512, 1024, 1, 4, ((0, 0), (3, 0))),               # the reference CLI's DEFAULT geometry (main.c:701-702, README "official setting"), one tile: direct kernels + split-K
+    (512, 1024, 5, 4, ((0, 0), (1, 2), (3, 4))),       # ... and as a 20-instance batch: the Winograd kernels at H up to 256
+    (256, 2048, 5, 4, ((0, 0), (2, 2), (3, 4))),       # the CLI's upper clamp F = 2048 (main.c:745-748) above 16 instances: the Winograd kernels at W up to 1024
+])
+def test_reference_default_and_widest_geometries(oracle, coeffs, T, F, ntiles, stems, taps):
+    """The geometries the reference ships with that no other test reaches: timeStep 512 x analyseBinLimit 1024 (its default) and the
+    widest tile it accepts, 2048 bins, at batch sizes that take the Winograd kernels.  Every tensor of the listed (stem, tile) instances
+    against the oracle, and the kernel families where the geometry fits."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=77 + T + F + ntiles)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    assert np.isfinite(masks).all()
+    worst = (0.0, 0.0)
+    for s, t in taps:
+        worst = max(worst, _check_taps(eng, oracle, coeffs(s), x[t], modes[s], s, t, masks, "T=%d F=%d x%d" % (T, F, ntiles)))
+    ks = _layer_kernels(eng, xd)
+    if ntiles * stems > 16:
+        for name in ("down3", "down4", "down5", "down6"):
+            assert ks[name].startswith("srt_enc_wino32<"), (name, ks[name])
+        for name in ("up1", "up2", "up3", "up4", "up5"):
+            assert ks[name].startswith("srt_dec_wino"), (name, ks[name])
+    else:
+        assert not any(v.startswith(("srt_dec_wino", "srt_enc_wino")) for v in ks.values()), ks
+    eng.close()
+    print("geometry %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
+
+
+def test_batch_invariant_across_the_up6_and_head_thresholds(oracle, coeffs):
+    """under batch_invariant the conv layers are pinned by geometry, but up6 (streamed kernel from 512 column workgroups) and the
+    head (rows kernel from 1024 workgroups) still switch with the batch.  Both pairs sum in the same order, so a tile alone and the same tile
+    inside a batch of 132 instances (both thresholds crossed, as the kernel names show) must be bit-identical."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S, NT = 64, 512, 4, 33
+    eng = _engine(F=F, T=T, stem_modes=(1, 0, 1, 0), variant=srt.VARIANT_VST, max_tiles=NT, batch_invariant=True)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, NT, T, F, seed=1311)
+    xd = torch.from_numpy(x).cuda()
+    big = eng.forward(xd).clone()
+    kb = _layer_kernels(eng, xd)
+    one = xd[17:18].contiguous()
+    alone = eng.forward(one).clone()
+    ka = _layer_kernels(eng, one)
+    assert kb["up6"].startswith("srt_up6_stream_kernel") and not ka["up6"].startswith("srt_up6_stream_kernel"), (kb["up6"], ka["up6"])
+    assert kb["up7"].startswith("srt_head_rows_kernel") and not ka["up7"].startswith("srt_head_rows_kernel"), (kb["up7"], ka["up7"])
+    assert torch.equal(alone[:, 0], big[:, 17])
     eng.close()

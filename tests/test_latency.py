@@ -8,8 +8,11 @@ host/rt_latency.c (plain C over include/Spleeter4Stems.h) drives TWO instances f
 F = 1536, T = 256 (PluginProcessor.cpp:124) for 3*T hops each, one hop per call, and times every call.  Bounds (wall time per call,
 p99 over the run, each instance): ordinary hops < 2 ms, the T-hop join hops < 5 ms - 9 % and 22 % of the hop period - both with calls
 back to back (the GPU never idles; the instances' hop and network streams contend) and paced at the real hop period (the GPU idles
-between calls).  Initialisation (weight upload, packing, workspace allocation, hipGraph capture) is timed separately and is NOT part
-of any call.  The numbers go to gpurun_out/r03_latency.json (copied to profiles/ for the record)."""
+between calls).  The WORST call of every run must stay under the hop period itself (23.2 ms: the contract proper; the recorded runs show
+isolated ~1 ms spikes, host scheduling).  Initialisation (weight upload, packing, workspace allocation, hipGraph capture) is timed
+separately and is NOT part of any call.  A third run drives EIGHT instances at once (eight plugin instances in one DAW on one GPU;
+nothing batches their hops across instances - each owns its hop stream and its network stream) and holds p99 under the hop period:
+that is the measured limit statement for the un-batched hop path.  The numbers go to gpurun_out/r04_latency.json (copied to profiles/)."""
 import json
 import os
 import subprocess
@@ -22,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "host")
 F, T = 1536, 256
 ORDINARY_P99_US, JOIN_P99_US = 2000.0, 5000.0
+HOP_US = 1024 / 44100 * 1e6
 
 
 def test_streaming_call_latency_two_instances(tmp_path, coeffs):
@@ -32,22 +36,28 @@ def test_streaming_call_latency_two_instances(tmp_path, coeffs):
             np.ascontiguousarray(coeffs(k), np.float32).tofile(f)
     record = {"geometry": {"F": F, "T": T}, "bounds_us": {"ordinary_p99": ORDINARY_P99_US, "join_p99": JOIN_P99_US},
               "hop_period_us": 1024 / 44100 * 1e6, "runs": {}}
-    for tag, pace, hops in (("back_to_back", 0, 3 * T), ("real_time_paced", 23220, T + T // 4)):
+    # back to back: 10 T hops = 10 join hops per instance (the join statistics need more than the 3 samples of 3 T hops)
+    for tag, pace, hops, ni in (("back_to_back", 0, 10 * T, 2), ("real_time_paced", 23220, T + T // 4, 2), ("eight_instances_back_to_back", 0, 3 * T, 8)):
         out = tmp_path / (tag + ".json")
-        subprocess.check_call([os.path.join(HOST, "rt_latency"), str(F), str(T), str(hops), str(w), str(pace), str(out), "2"], timeout=600)
+        subprocess.check_call([os.path.join(HOST, "rt_latency"), str(F), str(T), str(hops), str(w), str(pace), str(out), str(ni)], timeout=900)
         r = json.load(open(out))
         record["runs"][tag] = r
-        assert len(r["instances"]) == 2
+        assert len(r["instances"]) == ni
         for i, inst in enumerate(r["instances"]):
             assert inst["init_error"] == "", "%s instance %d came up muted: %s" % (tag, i, inst["init_error"])
             o, j = inst["ordinary_hops"], inst["join_hops"]
             assert o["p50_us"] > 20.0, "%s instance %d: calls return in %.1f us - no GPU work is being done" % (tag, i, o["p50_us"])
             assert j["n"] == hops // T and o["n"] == hops - hops // T
-            assert o["p99_us"] < ORDINARY_P99_US, "%s instance %d ordinary hops: %r" % (tag, i, o)
-            assert j["p99_us"] < JOIN_P99_US, "%s instance %d join hops: %r" % (tag, i, j)
+            if ni == 2:
+                assert o["p99_us"] < ORDINARY_P99_US, "%s instance %d ordinary hops: %r" % (tag, i, o)
+                assert j["p99_us"] < JOIN_P99_US, "%s instance %d join hops: %r" % (tag, i, j)
+                assert max(o["max_us"], j["max_us"]) < HOP_US, "%s instance %d: a call took longer than a hop period: %r %r" % (tag, i, o, j)
+            else:                                              # eight un-batched instances: the contract itself, with the worst call bounded by two periods
+                assert o["p99_us"] < HOP_US and j["p99_us"] < HOP_US, "%s instance %d: %r %r" % (tag, i, o, j)
+                assert max(o["max_us"], j["max_us"]) < 2 * HOP_US, "%s instance %d: %r %r" % (tag, i, o, j)
             if hops > 2 * T:
                 assert inst["output_peak"] > 1e-4              # the stream is past its 2T hops of silence: real audio came out
     print("latency:", json.dumps(record["runs"]))
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        json.dump(record, open(os.path.join(d, "r03_latency.json"), "w"), indent=1)
+        json.dump(record, open(os.path.join(d, "r04_latency.json"), "w"), indent=1)

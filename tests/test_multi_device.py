@@ -1,0 +1,104 @@
+"""GPU tests of the native (C) multi-device host, csrc/srt_multi.hip + host/spleeterrt_cli.c: the reference CLI's tile-range fan-out
+(Executable/main.c:544-673) with a GPU per worker.  The test box has ONE GPU, so the workers are several engines on device 0 - the partition,
+the per-worker threads, the weight distribution (RCCL clique of the distinct devices: a communicator of one still loads librccl and runs the
+broadcast) and the 3072-sample seam join are the code an 8-GPU node runs; what one GPU cannot show is a scaling curve."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "host")
+
+
+def _write_wav16(path, L, R):
+    import struct
+    q = np.clip(np.round(np.stack([L, R], 1) * 32768.0), -32768, 32767).astype("<i2")
+    data = q.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"data" + struct.pack("<I", len(data)) + data)
+    return q.astype(np.float32) / 32768.0
+
+
+def _read_wav_f32(path):
+    b = open(path, "rb").read()
+    i = b.index(b"data")
+    n = int.from_bytes(b[i + 4:i + 8], "little")
+    return np.frombuffer(b[i + 8:i + 8 + n], "<f4").reshape(-1, 2)
+
+
+@pytest.mark.parametrize("stems", [2, 3])
+def test_cli_program_with_several_gpu_workers(tmp_path, oracle, stems):
+    """spleeterrt_cli with SPLEETERRT_DEVICES=0,0 and 0,0,0 (two / three workers, each its own engine + host thread, on the one GPU) writes the
+    same files as the single-engine run: only the overlap-add association at the range seams differs (<= 2e-6 of the peak; kernel choice
+    pinned with SPLEETERRT_BATCH_INVARIANT).  The weights reach every engine through the RCCL broadcast path (librccl is loaded: `weights=rccl`)."""
+    cli = os.path.join(HOST, "spleeterrt_cli")
+    subprocess.check_call(["make", "-s", "-C", HOST, "spleeterrt_cli"])
+    h = np.concatenate([oracle.synth_coeff_fp16(1), oracle.synth_coeff_fp16(0)])
+    h.tofile(tmp_path / "weights.f16")
+    n = 441000                                                  # 10 s: 440 rows = 6 full tiles of 64 + a ragged 7th
+    L, R = oracle.synth_audio(n, 4321, True)
+    _write_wav16(tmp_path / "long.wav", L * 4.0, R * 4.0)
+    outs, texts = {}, {}
+    for tag, extra in (("one", {}), ("two", {"SPLEETERRT_DEVICES": "0,0"}), ("three", {"SPLEETERRT_DEVICES": "0,0,0", "SPLEETERRT_MAX_TILES": "2"}),
+                       ("peer", {"SPLEETERRT_DEVICES": "0,0", "SPLEETERRT_NO_RCCL": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        env = dict(os.environ, SPLEETERRT_VARIANT="exe", SPLEETERRT_BATCH_INVARIANT="1", **extra)
+        texts[tag] = subprocess.check_output([cli, "1", "64", "512", str(stems), str(tmp_path / "long.wav"), str(tmp_path / "weights.f16")], cwd=d, env=env).decode()
+        outs[tag] = {nm: _read_wav_f32(d / ("long.wav_%s.wav" % nm)) for nm in ["Vocal", "Accompaniment"] + (["Drum"] if stems == 3 else [])}
+    assert "engines=2" in texts["two"] and "weights=rccl broadcasts=2" in texts["two"], texts["two"]
+    assert "engines=3" in texts["three"] and "in chunks of 2" in texts["three"], texts["three"]          # 3 tiles per worker, walked 2 + 1
+    assert "weights=peer-copy" in texts["peer"], texts["peer"]
+    for tag in ("two", "three", "peer"):
+        for nm, r in outs["one"].items():
+            a = outs[tag][nm]
+            assert a.shape == r.shape == (n, 2)
+            assert np.abs(a - r).max() <= 2e-6 * np.abs(r).max(), (tag, nm, float(np.abs(a - r).max() / np.abs(r).max()))
+    for nm in outs["two"]:                                      # the weights' route changes nothing
+        assert np.array_equal(outs["two"][nm], outs["peer"][nm])
+
+
+def test_multi_engine_stream_equals_single_engine(oracle, coeffs):
+    """srtMultiSeparateHost (4 sub-networks on the same input, three engines on device 0, ragged last range) == one engine's
+    srtSeparateHostStream, and the library maps librccl only once a multi-device object exists."""
+    import spleeterrt_amd as srt
+    from spleeterrt_amd.capi import _Config
+    lib = srt.load_library()
+    T, F, S = 64, 512, 4
+    n = 4096 * 70 + 8192 + 700                                  # 289 rows -> 5 tiles: ranges of 2 / 2 / 1 (ragged) tiles
+    Lh, Rh = oracle.synth_audio(n, 99, True)
+    eng = srt.Engine(F=F, T=T, stem_modes=(1, 0, 1, 1), variant=srt.VARIANT_VST, max_tiles=2, batch_invariant=True)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    ref = eng.separate_host_stream(Lh, Rh)
+    eng.close()
+    cfg = _Config()
+    cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.batch_invariant = F, T, S, srt.VARIANT_VST, 2, 1
+    for i, m in enumerate((1, 0, 1, 1)):
+        cfg.stem_mode[i] = m
+        cfg.oob_weight[i] = 0.1
+    devs = (C.c_int * 3)(0, 0, 0)
+    h = C.c_void_p()
+    assert lib.srtMultiCreate(C.byref(cfg), devs, 3, C.byref(h)) == 0, lib.srtLastError()
+    assert "librccl" in open("/proc/self/maps").read()
+    for s in range(S):
+        c = np.ascontiguousarray(coeffs(s), np.float32)
+        assert lib.srtMultiSetCoeffHost(h, s, c.ctypes.data_as(C.c_void_p)) == 0, lib.srtLastError()
+    rows = lib.srtStftRows(n)
+    out = np.full((S, 2, lib.srtIstftLength(rows)), np.nan, np.float32)
+    assert lib.srtMultiSeparateHost(h, Lh.ctypes.data_as(C.c_void_p), Rh.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), 0) == 0, lib.srtLastError()
+    info = C.create_string_buffer(256)
+    assert lib.srtMultiInfo(h, info, 256) == 3 and b"distinct=1 weights=rccl broadcasts=4" in info.value, info.value
+    again = np.empty_like(out)
+    assert lib.srtMultiSeparateHost(h, Lh.ctypes.data_as(C.c_void_p), Rh.ctypes.data_as(C.c_void_p), n, again.ctypes.data_as(C.c_void_p), 0) == 0
+    lib.srtMultiDestroy(h)
+    assert out.shape == ref.shape and np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max(), float(np.abs(out - ref).max() / np.abs(ref).max())
+    assert np.array_equal(out, again)                           # reusable, deterministic
+    # bad device index: refused, nothing created
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.srtMultiCreate(C.byref(cfg), bad, 2, C.byref(h)) < 0 and b"device index" in lib.srtLastError()

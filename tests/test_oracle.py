@@ -138,6 +138,19 @@ def test_oracle_vs_reference_forward(oracle, coeffs):
             assert np.abs(oracle.forward(coeffs(stem), x, mode, variant) - yr).max() <= tol
 
 
+@pytest.mark.parametrize("T,F", [(256, 1024), (512, 1024), (256, 1536), (256, 2048)])
+def test_oracle_vs_reference_forward_at_shipped_tile_sizes(oracle, coeffs, T, F):
+    """The restatement pinned against the real reference network at the tile sizes the GPU tests check it at: BASELINE's 256 x 1024, the CLI's
+    default 512 x 1024 (main.c:701-702), the plugin's 256 x 1536 (PluginProcessor.cpp:124) and the CLI's widest, 2048 bins (main.c:745-748)."""
+    _need_ref(oracle)
+    x = _mag(oracle, 1, T, F, 31 + T + F)[0]
+    for flavour, variant, tol, stem, mode in (("vst", oracle.VARIANT_VST, 0.0, 3, 1), ("exe", oracle.VARIANT_EXE, 2.5e-7, 2, 0)):
+        net = oracle.RefNet(coeffs(stem), F, T, mode, flavour)
+        yr = net(x)
+        net.close()
+        assert np.abs(oracle.forward(coeffs(stem), x, mode, variant) - yr).max() <= tol
+
+
 def test_oracle_vs_reference_stft(oracle):
     _need_ref(oracle)
     n = 4096 * 4 + 8192

@@ -47,9 +47,27 @@ def test_bench_line_under_a_world_of_one_nccl_group():
     for d in (plain, dist):
         assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["kernel"].startswith("srt_")
     assert plain["layer_kernels"] == dist["layer_kernels"]
-    # same work, same kernels: the step time under the process group is the plain one within run-to-run noise
-    assert abs(dist["ms_per_step"] - plain["ms_per_step"]) <= 0.06 * plain["ms_per_step"], (plain["ms_per_step"], dist["ms_per_step"])
+    # same work, same kernels: joining the group must not change the step time beyond run-to-run noise (two separate processes, a shared box: a
+    # generous bound - what this catches is a collective or a sync that crept into the timed loop, which costs far more than 15 %)
+    assert abs(dist["ms_per_step"] - plain["ms_per_step"]) <= 0.15 * plain["ms_per_step"], (plain["ms_per_step"], dist["ms_per_step"])
     print("N=1 plain %.3f ms/step, N=1 under nccl world=1 %.3f ms/step" % (plain["ms_per_step"], dist["ms_per_step"]))
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x2"])
+def test_bench_fp16_modes_report_honest_rooflines(precision):
+    """the fp16-MFMA bench lines price their kernels against the fp16 MFMA peak (2.5 PFLOP/s dense) and the HBM roofline,
+    and no fraction anywhere in the line exceeds 1 (bench.py asserts it too; an earlier version divided fp16 work by the fp32 peak: frac 2.11)."""
+    d = _launch(["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--precision", precision], False)
+    rf = d["roofline"]
+    assert d["config"]["precision"] == precision and "_f16<" in rf["kernel"], rf["kernel"]
+    assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["hbm"]["frac"] <= 1.0 and 0.0 < rf["step"]["frac"] <= 1.0 and 0.0 < rf["step"]["hbm"]["frac"] <= 1.0
+    mf = rf.get("mfma", rf)
+    assert mf["peak"] == 2500.0
+    if precision == "f16":
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0      # SURVEY 8d: the fp16 path is HBM-bound
+    assert all(0.0 < v <= 1.0 for v in d["layer_executed_frac"].values()) and all(0.0 < v <= 1.0 for v in d["layer_hbm_frac"].values())
+    print("%s: %.3f ms/step, dominant %s: %s-bound frac %.3f (mfma %.3f, hbm %.3f); step mfma %.3f hbm %.3f" % (
+        precision, d["ms_per_step"], rf["kernel"], rf["bound"], rf["frac"], mf["frac"], rf["hbm"]["frac"], rf["step"]["frac"], rf["step"]["hbm"]["frac"]))
 
 
 def test_stream_c4_under_a_world_of_one_nccl_group(tmp_path):

@@ -73,6 +73,29 @@ def test_rank_span_matches_plan():
         assert offs[-1][0] + offs[-1][1] * 1024 + 3072 == stream.total_output_length(n)
 
 
+def test_c_partition_equals_rank_span():
+    """srtRankSpan - the C partition of the native multi-device host (csrc/srt_multi.hip, what host/spleeterrt_cli.c fans out with) - is the
+    same arithmetic as stream.rank_span for worlds 1 / 2 / 3 / 8 on the configs[3] length, a ragged short file, more ranks than tiles, and
+    the minimum length.  Pure host code: runs without a device."""
+    import ctypes as C
+    import spleeterrt_amd
+    from spleeterrt_amd.capi import Span as CSpan
+    lib = spleeterrt_amd.load_library()
+    lib.srtRankSpan.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(CSpan)]
+    for n, T in ((158769152, 256), (4096 * 108 + 8192, 64), (4096 * 108 + 8192, 256), (4096, 64), (1024 * 700 + 5, 128)):
+        for world in (1, 2, 3, 8, 11):
+            covered = 0
+            for r in range(world):
+                c = CSpan()
+                assert lib.srtRankSpan(n, T, r, world, C.byref(c)) == 0
+                sp = stream.rank_span(n, T, r, world)
+                assert (c.tile0, c.tile1, c.sample0, c.nsamples, c.frames, c.rows, c.out_offset) == tuple(sp), (n, T, world, r)
+                covered += c.rows
+            assert covered == stream.stft_rows(n)
+    c = CSpan()
+    assert lib.srtRankSpan(4096, 64, 2, 2, C.byref(c)) < 0 and lib.srtRankSpan(4096, 64, 0, 0, C.byref(c)) < 0      # rank outside the world
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
