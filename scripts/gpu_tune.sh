@@ -7,6 +7,7 @@
 # csrc/srt_nn.hip (SRT_TUNE_UP6: 1-9 tile shapes of the old kernel, 10 old kernel, 11 streamed kernel forced, 12-14 its ablations; SRT_TUNE_HEAD,
 # SRT_TUNE_HEADROWS=0|2|4).
 set -u
+export SRT_BENCH_NOCHECK=1      # ablation settings compute wrong results by construction
 TAG=${1:-tune}; PREC=${2:-f32}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

@@ -188,8 +188,10 @@ static int multi_distribute(srt_multi* m, int stem, int skip_engine)
         ++m->broadcasts;
         for (size_t i = 0; i < m->udev.size(); ++i) { hipSetDevice(m->udev[i]); if (hipStreamSynchronize(m->ustream[i]) != hipSuccess) return mfail(-2, "srtMultiSetCoeff: broadcast stream failed"); }
     } else {
+        hipSetDevice(m->udev[0]);
         for (size_t i = 1; i < m->udev.size(); ++i)
-            if (hipMemcpyPeer(m->blob[i], m->udev[i], m->blob[0], m->udev[0], count * 4) != hipSuccess) return mfail(-2, "srtMultiSetCoeff: hipMemcpyPeer failed");
+            if (hipMemcpyPeerAsync(m->blob[i], m->udev[i], m->blob[0], m->udev[0], count * 4, m->ustream[0]) != hipSuccess) return mfail(-2, "srtMultiSetCoeff: hipMemcpyPeer failed");
+        if (hipStreamSynchronize(m->ustream[0]) != hipSuccess) return mfail(-2, "srtMultiSetCoeff: peer copy failed");
     }
     for (size_t g = 0; g < m->eng.size(); ++g) {
         if ((int)g == skip_engine) continue;
@@ -206,7 +208,8 @@ int srtMultiSetCoeffHost(srt_multi* m, int stem, const void* h_coeff)
     if (!m || !h_coeff || stem < 0 || stem >= m->cfg.n_stems) return mfail(-1, "srtMultiSetCoeffHost: bad argument");
     int prev = 0; (void)hipGetDevice(&prev);
     hipSetDevice(m->udev[0]);
-    int rc = hipMemcpy(m->blob[0], h_coeff, srtCoeffBytes(), hipMemcpyHostToDevice) == hipSuccess ? 0 : mfail(-2, "srtMultiSetCoeffHost: upload failed");
+    int rc = hipMemcpyAsync(m->blob[0], h_coeff, srtCoeffBytes(), hipMemcpyHostToDevice, m->ustream[0]) == hipSuccess && hipStreamSynchronize(m->ustream[0]) == hipSuccess
+                 ? 0 : mfail(-2, "srtMultiSetCoeffHost: upload failed");
     if (!rc) rc = multi_distribute(m, stem, -1);
     hipSetDevice(prev);
     return rc;
@@ -219,8 +222,10 @@ int srtMultiSetCoeffFp16Host(srt_multi* m, int stem, const uint16_t* h_halfs)
     int prev = 0; (void)hipGetDevice(&prev);
     hipSetDevice(m->dev[0]);                                    // engine 0 lives on udev[0]
     int rc = srtSetCoeffFp16Host(m->eng[0], stem, h_halfs);
-    if (!rc && (hipStreamSynchronize(m->stream[0]) != hipSuccess ||
-                hipMemcpy(m->blob[0], srt_engine_coeff_device(m->eng[0], stem), srtCoeffBytes(), hipMemcpyDeviceToDevice) != hipSuccess)) rc = mfail(-2, "srtMultiSetCoeffFp16Host: copy failed");
+    // (on the engine's own stream and waited for: a device-to-device hipMemcpy on the null stream may return before the copy has run, and the
+    //  non-blocking streams that read the staging buffer next do not wait for the null stream)
+    if (!rc && (hipMemcpyAsync(m->blob[0], srt_engine_coeff_device(m->eng[0], stem), srtCoeffBytes(), hipMemcpyDeviceToDevice, m->stream[0]) != hipSuccess ||
+                hipStreamSynchronize(m->stream[0]) != hipSuccess)) rc = mfail(-2, "srtMultiSetCoeffFp16Host: copy failed");
     if (!rc) rc = multi_distribute(m, stem, 0);
     hipSetDevice(prev);
     return rc;

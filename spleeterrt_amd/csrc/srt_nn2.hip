@@ -417,6 +417,128 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
     if (DUAL && grp == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last loop barrier (its last MFMA segment ran beside this epilogue)
 }
 
+
+// ------------------------------------------------------------------------------------------- down1, streamed down a tile column
+// down1 (2 -> 16 channels, K = 50, all stems of a launch stacked into M because they read the same magnitudes) is a STORE kernel: 0.17 ms of matrix
+// time beside 1.07 GB of output at 64 tiles x 4 stems.  The one-shot form above (one 4 x 64 output tile per workgroup, three per CU) pays a prologue
+// (weight slab + patch through registers) and an epilogue (64 stores per lane, then the workgroup retires) per tile with only other workgroups to
+// cover them: 0.40 ms = 2.7 TB/s.  Here a 256-thread workgroup owns a 64-pixel wide COLUMN of one tile's output for every stem and walks down it four
+// output rows at a time:
+//   interval i:  wait for the input rows of chunk i + 1 (LDS-DMA issued one interval earlier) | barrier | issue the DMA of chunk i + 2 |
+//                100 MFMAs per wave (4 interleaved 32-pixel sub-tiles x 25 taps, A operands = the wave's 25 weight fragments, in registers for the
+//                whole column) | + bias, 16 x 16-byte stores per lane
+// The weights, the bias and the lane geometry are set up once per column (32 intervals), the input arrives by LDS-DMA only (buffer_load ... lds: zeros
+// outside the image, no registers in flight), and a wave never waits for its stores: vmcnt is one in-order queue and a wave's DMA pieces of an interval are
+// issued BEFORE that interval's stores, so `s_waitcnt vmcnt(16)` at the top of the next interval is "my pieces have landed" with the 16 stores still in flight.
+// Same MFMA chain as the kernel above (one K chunk: taps ascending, k-pair = the two input channels of a tap, + bias afterwards): bit-identical results,
+// so the switch between the two forms with the batch size is invisible (batch_invariant included).
+// Wave (mt, reg): M tile mt (32 stacked rows = 2 stems x 16 channels), output rows 2 reg + l31 / 16 of the interval; lane l31 of sub-tile nr owns pixel
+// 4 (l31 % 16) + nr: four consecutive pixels of every channel row per lane = one float4 store.
+// Input ring in LDS: 32 rows x 2 channels x 144 floats (input columns 2 ox0 - 4 .. 2 ox0 + 139), row r of the image at ring row r & 31; chunk c = rows
+// 8 c .. 8 c + 7 = 9 DMA pieces.  Interval i reads rows 8 i - 1 .. 8 i + 9: chunks i - 1 (its last row), i, i + 1 while chunk i + 2 lands.
+#define SRT_D1S_PITCH 144
+typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
+template <int ABL = 0>                                                          // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
+__global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvParams p)
+{
+    constexpr int PITCH = SRT_D1S_PITCH, RING = 32, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64;      // 576 float4 = 9 pieces per chunk
+    static_assert(CH_F4 % 64 == 0 && NPIECE == 9, "a chunk is whole DMA pieces");
+    __shared__ __attribute__((aligned(16))) float s_ring[RING * 2 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 1, reg = wave >> 1;
+    const int Ho = p.H >> 1, Wo = p.W >> 1, strips = Wo / 64;
+    const int pos = srt_xcd_order(strips * p.ntiles), ox0 = (pos % strips) * 64, tile = pos / strips;
+    const int mlimit = p.stack * 16;
+    // A operands: w[stacked row][channel = half][tap] from the stem-stacked pack [2][25][CP2]; rows past the last stem are zero in the pack
+    float a[25];
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap) a[tap] = p.wpack2[(size_t)(half * 25 + tap) * p.CP2 + mt * 32 + l31];
+    // output rows of this lane's 16 accumulator registers: stacked row m = 32 mt + (r & 3) + 8 (r >> 2) + 4 half -> (stem, channel)
+    float bi[16]; unsigned ob[16];
+    const size_t ohw = (size_t)Ho * Wo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1), st = m >> 4, co = m & 15;
+        bi[r] = p.bias[st * p.coeff_stem + co];
+        ob[r] = (unsigned)(st * p.out_stem + (size_t)co * ohw);                 // (the launcher checks that the output tensor has fewer than 2^32 elements)
+    }
+    const bool ok_lo = mt * 32 < mlimit, ok_hi = mt * 32 + 16 < mlimit;         // wave-uniform: registers 0..7 are one stem's channels, 8..15 the next stem's
+    const int nst = ABL == 1 ? 0 : (ok_lo ? 8 : 0) + (ok_hi ? 8 : 0);          // stores this wave issues per interval
+    const int oyl = 2 * reg + (l31 >> 4), oxl = 4 * (l31 & 15);
+    float* outp = p.outRaw + (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl;
+    // ---- DMA: float4 e = piece * 64 + lane of a chunk = (row * 2 + ch) * 36 + j  <-  channel ch, image row 8 c + row, columns 2 ox0 - 4 + 4 j .. + 3
+    constexpr unsigned OOR = 0x80000000u;
+    const size_t hw = (size_t)p.H * p.W;
+    unsigned voff[3]; int vrow[3]; unsigned pdst[3];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_ring;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int piece = min(wave + 4 * q, NPIECE - 1), e = piece * 64 + lane;
+        const int j = e % (PITCH / 4), rc = e / (PITCH / 4), ch = rc & 1, row = rc >> 1, gx = 2 * ox0 - 4 + 4 * j;
+        vrow[q] = row;
+        voff[q] = (j < 34 && gx >= 0 && gx + 3 < p.W) ? 4u * (unsigned)((size_t)ch * hw + (size_t)row * p.W + gx) : OOR;
+        pdst[q] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(piece * 1024));
+    }
+    const size_t src_ = (size_t)(p.srcA + (size_t)tile * p.srcA_tile);
+    srt_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)src_); rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(src_ >> 32) & 0xffffu));
+    rs.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)8 * hw); rs.w = 0x00020000;
+    auto dma_chunk = [&](int c) {
+        const unsigned adv = 4u * (unsigned)(8 * c * p.W), base = (unsigned)((c & 3) * 8 * 2 * PITCH * 4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned vo = (voff[q] != OOR && 8 * c + vrow[q] < p.H) ? voff[q] + adv : OOR;
+            const unsigned dst = pdst[q] + base;
+            asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo), "s"(rs), "s"(dst) : "memory");
+        }
+    };
+    // image row -1 (ring row 31) is zero padding; chunk 3 overwrites it long after interval 0 has read it
+    for (int e = tid; e < 2 * PITCH; e += 256) s_ring[31 * 2 * PITCH + e] = 0.0f;
+    dma_chunk(0); dma_chunk(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
+    const int lcol = 2 * oxl + 3;                                              // ring column of input column 2 ox - 1 (kx = 0, nr = 0)
+    const int nint = Ho / 4;
+    for (int i = 0; i < nint; ++i) {
+        // my pieces of chunk i + 1 (issued during interval i - 1, before its 16 stores) have landed; the stores may still be in flight
+        if (nst == 16) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));      // vmcnt(16)
+        else if (nst == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                                                        // everyone's pieces; everyone is done with chunk i - 2 (the slot chunk i + 2 lands in)
+        dma_chunk(i + 2);                                                       // (past the image: zeros)
+        int ro[5];
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) ro[ky] = ((((8 * i + 2 * oyl + ky - 1) & (RING - 1)) * 2 + half) * PITCH) + lcol;
+        f32x16 acc[4];
+        if (ABL != 2) {
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                const int ky = tap / 5, kx = tap % 5;
+#pragma unroll
+                for (int nr = 0; nr < 4; ++nr) {
+                    const float b = s_ring[ro[ky] + kx + 2 * nr];
+                    if (tap == 0) { f32x16 z; for (int r = 0; r < 16; ++r) z[r] = 0.0f; acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b, z, 0, 0, 0); }
+                    else acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap], b, acc[nr], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nr = 0; nr < 4; ++nr) for (int r = 0; r < 16; ++r) acc[nr][r] = s_ring[ro[0] + nr + r];
+        }
+        float* orow = outp + (size_t)(4 * i) * Wo;
+        if (ABL != 1 || p.ntiles < 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < 8 ? ok_lo : ok_hi) {
+                    float4 v;
+                    v.x = acc[0][r] + bi[r]; v.y = acc[1][r] + bi[r]; v.z = acc[2][r] + bi[r]; v.w = acc[3][r] + bi[r];
+                    *reinterpret_cast<float4*>(orow + ob[r]) = v;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- decoder v2
 // CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0, bool SPLITK = false, bool DUAL = false>
@@ -846,6 +968,9 @@ static bool srt_use_dual() { return tune("dual") != 0; }
 #else
 constexpr bool srt_use_dual() { return false; }
 #endif
+#ifndef SRT_DOWN1_STREAM_DEFAULT
+#define SRT_DOWN1_STREAM_DEFAULT 1
+#endif
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool STK>
 static int launch_enc2_cfg(const SrtConvParams& p, hipStream_t s)
 {
@@ -934,6 +1059,24 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     if (p.Cin == 2) {                                                                    // down1, stem-stacked M
         if (!p.wpack2 || p.stack < 1 || p.Cout != 16) return 1;       // the stacked epilogue maps 16 rows to a stem
         if (p.stack * p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+        // batches that give every CU two column workgroups: the streamed form (bit-identical to the tiled one; see srt_down1_stream_kernel)
+        {
+            const int Ho = p.H / 2;
+            int streamed = SRT_DOWN1_STREAM_DEFAULT;
+#ifdef SRT_TUNING
+            if (getenv("SRT_TUNE") && strstr(getenv("SRT_TUNE"), "d1s=")) streamed = tune("d1s");      // d1s=0 tiled kernel, 2 / 3: ablations
+#endif
+            if (streamed && p.stack * p.Cout <= 64 && p.CP2 >= 64 && !p.out16 && !p.ws && Wo % 64 == 0 && Ho % 4 == 0 && (long)(Wo / 64) * p.ntiles >= 384 &&
+                (size_t)p.stack * p.out_stem < ((size_t)1 << 32) && (size_t)8 * p.H * p.W < 0x7fffffffu) {
+                const dim3 grid((unsigned)((Wo / 64) * p.ntiles));
+#ifdef SRT_TUNING
+                if (streamed == 2) { SRT_LAUNCH((srt_down1_stream_kernel<1>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
+                if (streamed == 3) { SRT_LAUNCH((srt_down1_stream_kernel<2>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
+#endif
+                SRT_LAUNCH((srt_down1_stream_kernel<0>), grid, dim3(256), 0, s, p);
+                return srt_launch_status();
+            }
+        }
 #ifdef SRT_TUNING
         switch (tune("down1")) {
         case 1: return launch_enc2_cfg<64, 2, 32, 4, 2, 1, 2, true>(p, s);              // 2 rows x 128 cols

@@ -817,8 +817,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 //   * the input must already be act(BN(raw)) - the non-linearity cannot ride through the transform - so the PRODUCER of the tensor supplies
 //     that copy (the engine keeps one for the inputs of the layers that run here) and this kernel writes its own when p.outAct is set;
 //   * the four classes ADD into the same 2 x 2 outputs, and they live in four different waves: at the end of a unit the waves exchange their
-//     classes' outputs through 32 KiB of LDS, one M block at a time, and each lane finishes one of its four channels (+ bias -> raw, and
-//     act(BN(.)) -> the copy for the next layer).
+//     classes' outputs through LDS (24 KiB per M block; the second M block borrows the U ring slot the unit has just finished with) and each
+//     lane finishes one of its four channels (+ bias -> raw, and act(BN(.)) -> the copy for the next layer): two barriers per unit.
 template <int BA, int BB, int NI, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
@@ -830,7 +830,8 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
     constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;
     static_assert(DPW == 5 && NPP >= 7 && NPP <= 14, "piece map: per wave three U pieces, one U-or-patch piece, one patch piece");
-    constexpr int XBUF = 4 * 2 * 16 * 16 * 4;                                // class exchange: [class][group][channel of the M block][block][2 x 2 outputs]
+    constexpr int XBUF = 4 * 2 * 4 * 3 * 16 * 4;                             // class exchange of one M block: [writer class][group][kq][3 published channels][block][2 x 2 outputs] = 24 KiB
+    static_assert(XBUF <= UBUF, "the second M block's exchange lives in a U ring slot");
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF + XBUF];
     float* s_u = s_all;
     float* s_p = s_all + UR * UBUF;
@@ -1052,32 +1053,59 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
             kstep(k, su, sp1, sd, sd1);
             su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
         }
-        // ---- unit epilogue: the four classes' 2 x 2 outputs meet in LDS, one M block at a time; lane (kq, l15) of the class-c wave finishes channel
-        // 4 kq + c of the M block for its block: sum in the fixed order (C11 + C10) + (C01 + C00), + bias -> raw; act(BN(.)) -> the copy
+        // ---- unit epilogue: the four classes' 2 x 2 outputs of a (channel, block) live in four waves and meet in LDS.  Lane (kq, l15) of the class-c
+        // wave finishes channel 4 kq + c of each M block for its block: sum in the fixed order (C11 + C10) + (C01 + C00), + bias -> raw; act(BN(.)) ->
+        // the copy.  It keeps its OWN class's term of that channel in registers and publishes only the three channels the other classes' lanes
+        // finish: X[writer class][g][kq][pr][l15] float4 (pr = rank of the channel among those three), 24 KiB per M block.  M block 0 goes to the
+        // dedicated buffer; M block 1 to the U ring slot the unit's last K step has just finished with (slot sd after the loop's increment: the next
+        // DMA into it is issued behind the NEXT K step's barrier, after every wave has read its terms).  Two barriers per unit (round 3: four, one
+        // M block at a time through one 32 KiB buffer):
+        //   transform both M blocks, write X0 | barrier (everyone is past the last K step: the ring slot is free; X0 complete) |
+        //   write X1, read X0, finish M block 0 | barrier (X1 complete) | read X1, finish M block 1
         set_out_unit(unit0 + t);
+        // ABL (tuning builds, wrong results): 6 no epilogue (the accumulators stay alive through a store that never executes), 7 epilogue without its two
+        // barriers, 8 without its global stores, 9 without the LDS exchange
+        if constexpr (ABL == 6) {
+            if (p.ntiles < 0) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float m[NP];
-#pragma unroll
-                for (int x = 0; x < NP; ++x) m[x] = acc[mb][x][r];
-                float y[2][2];
-                wino_out2d<NY, NX>(m, y);
-                *reinterpret_cast<float4*>(&s_x[((((CLS * 2 + g) * 16) + 4 * kq + r) * 16 + l15) * 4]) = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+                    for (int x = 0; x < NP; ++x) *reinterpret_cast<f32x4*>(p.outRaw + (size_t)(mb * NP + x) * 4) = acc[mb][x];
             }
-            __syncthreads();
-            {
-                const int ch = 4 * kq + CLS;
+        } else {
+            float4 own[2], pub1[3];
+            float* x1 = s_u + sd * UBUF;
+            const int xo = (((CLS * 2 + g) * 4 + kq) * 3) * 64 + l15 * 4;          // this lane's three float4 slots (writer view), + pr * 64
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float m[NP];
+#pragma unroll
+                    for (int x = 0; x < NP; ++x) m[x] = acc[mb][x][r];
+                    float y[2][2];
+                    wino_out2d<NY, NX>(m, y);
+                    const float4 y4 = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+                    if (r == CLS) own[mb] = y4;
+                    else if (mb == 0) { if constexpr (ABL != 9) *reinterpret_cast<float4*>(&s_x[xo + (r < CLS ? r : r - 1) * 64]) = y4; else own[0].x += y4.y; }
+                    else pub1[r < CLS ? r : r - 1] = y4;
+                }
+            }
+            if constexpr (ABL != 7 && ABL != 9) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { if constexpr (ABL != 9) *reinterpret_cast<float4*>(&x1[xo + j * 64]) = pub1[j]; else own[1].x += pub1[j].y; }
+            auto finish = [&](int mb, const float* xb) __attribute__((always_inline)) {
                 float4 c4[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) c4[c] = *reinterpret_cast<const float4*>(&s_x[((((c * 2 + g) * 16) + ch) * 16 + l15) * 4]);
-                const int co = m0 + 16 * mb + ch;
+                for (int c = 0; c < 4; ++c)                                     // class c's term of channel 4 kq + CLS: its lane (g, kq, l15), slot pr(CLS)
+                    if (c != CLS) { if constexpr (ABL != 9) c4[c] = *reinterpret_cast<const float4*>(&xb[((((c * 2 + g) * 4 + kq) * 3) + (CLS < c ? CLS : CLS - 1)) * 64 + l15 * 4]); else c4[c] = own[mb]; }
+                c4[CLS] = own[mb];
+                const int co = m0 + 16 * mb + 4 * kq + CLS;
                 const float bias = ebias[mb];
                 float o[4];
                 o[0] = ((c4[0].x + c4[1].x) + (c4[2].x + c4[3].x)) + bias; o[1] = ((c4[0].y + c4[1].y) + (c4[2].y + c4[3].y)) + bias;
                 o[2] = ((c4[0].z + c4[1].z) + (c4[2].z + c4[3].z)) + bias; o[3] = ((c4[0].w + c4[1].w) + (c4[2].w + c4[3].w)) + bias;
-                if (blk_ok) {
+                if (ABL == 8 ? (blk_ok && p.ntiles < 0) : blk_ok) {
                     float* dst = p.outRaw + obase + (size_t)co * ohw;
                     *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
                     *reinterpret_cast<float2*>(dst + Wo) = make_float2(o[2], o[3]);
@@ -1088,8 +1116,10 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
                         *reinterpret_cast<float2*>(da + Wo) = make_float2(srt_enc_epilogue(o[2], sc, sf, actp), srt_enc_epilogue(o[3], sc, sf, actp));
                     }
                 }
-            }
-            __syncthreads();                                                 // the exchange buffer is free again
+            };
+            finish(0, s_x);
+            if constexpr (ABL != 7 && ABL != 9) __syncthreads();
+            finish(1, x1);
         }
         if (t + 1 < tpw) {
 #pragma unroll
@@ -1278,6 +1308,19 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
     if (Ho >= 4 && Wo >= 32) {
         const long units = (long)((Wo + 31) / 32) * ((Ho + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
+#ifdef SRT_TUNING
+        const dim3 grid((unsigned)(wgs / tpw));
+        switch (wino_tune("encabl=")) {                                      // timing ablations (wrong results): 1 no barrier, 3 no U DMA, 4 no transform, 5 no A reads, 6 no epilogue, 7 / 8 / 9 epilogue without barriers / stores / exchange
+        case 1: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 3: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 4: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 5: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 6: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 6>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 7: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 7>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 8: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 8>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 9: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 9>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        }
+#endif
         SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
     } else if (Ho >= 4 && Wo >= 16) {
         const long units = (long)((Wo + 15) / 16) * ((Ho + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;

@@ -762,7 +762,7 @@ def test_full_size_batch_properties(oracle, coeffs):
 
 # ------------------------------------------------------------------ the launch shapes the headline is timed on, per tap
 SHIPPED_KERNELS = {      # bench.py's `layer_kernels` at 64 tiles x 4 stems of 256 x 1024 (profiles/r0x_bench_n1.json); template arguments may move with tuning, the families may not
-    "down1": "srt_enc_mfma2<", "down2": "srt_enc_mfma2<", "down3": "srt_enc_wino32<", "down4": "srt_enc_wino32<", "down5": "srt_enc_wino32<", "down6": "srt_enc_wino32<",
+    "down1": "srt_down1_stream_kernel<", "down2": "srt_enc_mfma2<", "down3": "srt_enc_wino32<", "down4": "srt_enc_wino32<", "down5": "srt_enc_wino32<", "down6": "srt_enc_wino32<",
     "up1": "srt_dec_wino32<", "up2": "srt_dec_wino32<", "up3": "srt_dec_wino32<", "up4": "srt_dec_wino32<", "up5": "srt_dec_wino", "up6": "srt_up6_stream_kernel<", "up7": "srt_head_rows_kernel<",
 }
 
@@ -865,4 +865,42 @@ def test_batch_invariant_across_the_up6_and_head_thresholds(oracle, coeffs):
     assert kb["up6"].startswith("srt_up6_stream_kernel") and not ka["up6"].startswith("srt_up6_stream_kernel"), (kb["up6"], ka["up6"])
     assert kb["up7"].startswith("srt_head_rows_kernel") and not ka["up7"].startswith("srt_head_rows_kernel"), (kb["up7"], ka["up7"])
     assert torch.equal(alone[:, 0], big[:, 17])
+    eng.close()
+
+
+@pytest.mark.parametrize("T,F,ntiles,stems", [
+    (64, 1024, 48, 4),      # 8 column workgroups per tile x 48 tiles = 384: the smallest batch that takes the streamed form; 8 intervals per column
+    (64, 1024, 50, 3),      # three stems: the second M tile is half empty (its upper 16 rows are no stem: 8 stores per interval instead of 16)
+    (128, 1536, 32, 4),     # 12 columns per tile, 16 intervals
+])
+def test_down1_streamed_form(oracle, coeffs, T, F, ntiles, stems):
+    """srt_down1_stream_kernel (down1 walked down 64-pixel output columns, round 4): conv1 of the first, an interior and the last tile of every stem
+    against the oracle, the kernel named by the engine, and bit-identity with the tiled kernel a one-tile launch takes (same MFMA chain: the
+    switch with the batch size must be invisible, batch_invariant included)."""
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, batch_invariant=True)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=4100 + F + ntiles)
+    xd = torch.from_numpy(x).cuda()
+    eng.forward(xd)
+    got = {(s, t): eng.tensor("conv1", s, t) for s in range(stems) for t in (0, ntiles // 2 + 1, ntiles - 1)}
+    ks = _layer_kernels(eng, xd)
+    assert ks["down1"].startswith("srt_down1_stream_kernel<"), ks["down1"]
+    lo = oracle.layout()
+    for (s, t), g in got.items():
+        c = coeffs(s)
+        w = c[lo.down[0].w:lo.down[0].w + 25 * 2 * 16]
+        ref = oracle.conv5x5_s2(x[t], w, 16) + c[lo.down[0].b:lo.down[0].b + 16][:, None, None]
+        assert g.shape == ref.shape
+        assert _rel_rms(g, ref) < TAP_RMS_TOL and np.abs(g - ref).max() < TAP_MAX_TOL * np.abs(ref).max(), (s, t, _rel_rms(g, ref))
+    for t in (0, ntiles - 1):                                   # the tiled kernel on the same tile: bit-identical
+        one = torch.from_numpy(x[t:t + 1]).cuda()
+        eng.forward(one)
+        k1 = _layer_kernels(eng, one)
+        assert k1["down1"].startswith("srt_enc_mfma2<"), k1["down1"]
+        for s in range(stems):
+            assert np.array_equal(eng.tensor("conv1", s, 0), got[(s, t)]), (s, t)
     eng.close()

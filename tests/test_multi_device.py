@@ -48,8 +48,9 @@ def test_cli_program_with_several_gpu_workers(tmp_path, oracle, stems):
         d = tmp_path / tag
         d.mkdir()
         env = dict(os.environ, SPLEETERRT_VARIANT="exe", SPLEETERRT_BATCH_INVARIANT="1", **extra)
-        texts[tag] = subprocess.check_output([cli, "1", "64", "512", str(stems), str(tmp_path / "long.wav"), str(tmp_path / "weights.f16")], cwd=d, env=env).decode()
+        texts[tag] = subprocess.check_output([cli, "3" if tag == "one" else "1", "64", "512", str(stems), str(tmp_path / "long.wav"), str(tmp_path / "weights.f16")], cwd=d, env=env).decode()
         outs[tag] = {nm: _read_wav_f32(d / ("long.wav_%s.wav" % nm)) for nm in ["Vocal", "Accompaniment"] + (["Drum"] if stems == 3 else [])}
+    assert "spawnNthreads 3: 1 device worker(s) used (1 device(s)" in texts["one"], texts["one"]      # more workers asked for than the node has GPUs
     assert "engines=2" in texts["two"] and "weights=rccl broadcasts=2" in texts["two"], texts["two"]
     assert "engines=3" in texts["three"] and "in chunks of 2" in texts["three"], texts["three"]          # 3 tiles per worker, walked 2 + 1
     assert "weights=peer-copy" in texts["peer"], texts["peer"]
