@@ -142,6 +142,9 @@ template <int X> __device__ __forceinline__ float wino_point(const float (&t3)[4
     if constexpr (y3) return i == 0 ? c(0) - c(2) : i == 1 ? c(1) + c(2) : i == 2 ? c(2) - c(1) : c(1) - c(3);
     else return i == 0 ? c(0) - c(1) : i == 1 ? c(1) : c(1) - c(2);      // (patch row 3 is not used by the even output rows)
 }
+// C operand of a K step's MFMAs: the accumulator, or - first K step of a unit - the constant 0 (an inline operand: the unit's accumulators are never
+// zeroed with 64-128 v_mov per wave; same bits, 0 + a b either way)
+template <bool FIRST> __device__ __forceinline__ f32x4 wino_c(const f32x4& acc) { if constexpr (FIRST) return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; else return acc; }
 template <int I, int N> struct WinoFor {                                    // compile-time loop: f(integral_constant<I>) ... f(integral_constant<N-1>)
     template <class F> static __device__ __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); WinoFor<I + 1, N>::run(f); }
 };
@@ -212,6 +215,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI, MB = p.Cout / 16;
     const int walk = (tpw >> 9) & 1;                                         // column walk (wino_sp_xy)
+    const bool mfast = ((tpw >> 10) & 1) != 0;                               // M-block pair fastest in the launch order (see srt_dec_wino32)
     tpw &= 255;
     const int colrun = !walk ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     // A workgroup walks `tpw` consecutive (instance group, spatial tile) units of one (stem, M block): same U slabs, and the first
@@ -351,10 +355,6 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         set_dma_unit(unit0);
         if (CS) { if (tpw > 1) set_dma_next(unit0 + 1); else dma_keep_as_next(); }
         issue_first();
-#pragma unroll
-        for (int x = 0; x < NP; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
         int slot = 0;                                                        // k % UR (CS: of the running step count): U slab k is in buffer `slot`, patch k+1 in slot+1; patch k+UR goes to `slot`
         auto unit_prologue = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): the unit's first slab and patches (and whatever the previous unit left in flight)
@@ -369,7 +369,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         if (CS) unit_prologue();
         for (int t = 0; t < tpw; ++t) {
         if (!CS) unit_prologue();
-        for (int k = 0; k < nk; ++k) {
+        auto kstep = [&](int k, auto fc) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(fc)::value;                      // first K step of a unit: C = 0
             // vmcnt((UR-2)(2 + PPW)): everything older than this wave's pieces of the last UR-2 steps has landed - its pieces of U slab k
             // and of patch k+1 (both issued in step k+1-UR).  After the barrier so have everyone's, and every wave is done with step k-1:
             // U buffer (k-1)%UR and patch slot k%UR are free.
@@ -395,11 +396,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 #pragma unroll
                     for (int i = 0; i < PPW; ++i) dma_patch(kp, slot, i);
                 }
-                acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], acc[4 * q], 0, 0, 0);
+                acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v[4 * q], wino_c<FIRST>(acc[4 * q]), 0, 0, 0);
                 if constexpr (nm > 1) {
-                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], acc[4 * q + 1], 0, 0, 0);
-                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], acc[4 * q + 2], 0, 0, 0);
-                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], acc[4 * q + 3], 0, 0, 0);
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v[4 * q + 1], wino_c<FIRST>(acc[4 * q + 1]), 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v[4 * q + 2], wino_c<FIRST>(acc[4 * q + 2]), 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v[4 * q + 3], wino_c<FIRST>(acc[4 * q + 3]), 0, 0, 0);
                 }
                 if constexpr (SB == 1) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ABL != 4) {
@@ -420,7 +421,9 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
                 __builtin_amdgcn_sched_barrier(0);                           // quads stay in order: bounded live ranges, no accumulator copies
             });
             slot = slot == UR - 1 ? 0 : slot + 1;
-        }
+        };
+        kstep(0, std::true_type{});
+        for (int k = 1; k < nk; ++k) kstep(k, std::false_type{});
 
         // ---- the next unit's first DMA goes out before this unit's epilogue.  Barrier: every wave is out of the K loop, so the U
         // buffers and patch slots are free (the refills the last K steps issued past the end target the same pieces from the same
@@ -456,13 +459,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
             else if (actp.ue != 0.0f) emit([&](float y, int r) { return srt_dec_epilogue(y, bi[r], sc[r], sf[r], actp); });
             else emit([&](float y, int r) { return srt_dec_epilogue_lin(y, bi[r], sc[r], sf[r], actp.lin); });
         }
-        if (t + 1 < tpw) {
-#pragma unroll
-            for (int x = 0; x < NP; ++x)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[x][r] = 0.0f;
-            if (CS && t + 2 < tpw) set_dma_next(unit0 + t + 2);              // (the DMA state itself moved on UR steps before the unit ended)
-        }
+        if (CS && t + 2 < tpw) set_dma_next(unit0 + t + 2);                  // (the DMA state itself moved on UR steps before the unit ended)
         }                                                                    // units
     };
     if (h) body(std::integral_constant<int, 1>{});
@@ -500,7 +497,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 // unit (instead of refetching the last ones as filler), and the next unit's first transformed patch comes out of the ordinary refills of the
 // last step, so a unit boundary is an epilogue and nothing else: no drained DMA queue, no extra barrier, no separate first transform.
 // NI: instances per workgroup (BA * BB * NI == 32 blocks): 1 for inputs of at least 4 x 32 pixels, 2 for 4 x 16 (up1: one instance is 16 blocks).
-template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0, int NI = 1>
+template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0, int NI = 1, int PEEL = 0>   // PEEL 1: a unit's first K step starts from C = 0 instead of zeroed accumulators (measured slower here, faster in srt_dec_wino)
 __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS && !(CS && EA), "rings (5 x 30 KiB = 150 KiB of LDS)");
@@ -528,7 +525,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     const int colrun = !(flags & 2) ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;      // workgroups per (stem, M-block pair)
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
-    const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
+    // launch order: (stem, M-block pair) slowest - an XCD works on one weight slab at a time (L2 resident) and re-reads the input from HBM once per pair -
+    // or, flag bit 2, the M-block pair FASTEST: the MB2 workgroups that read the same input patches are neighbours on one XCD and run in step (the
+    // patch is an L2 hit for all but the first), while the U slabs of all pairs of a stem share the L2 (layers whose weights are small)
+    const bool mfast = (flags & 4) != 0;
+    const int wsel = pos / upw, mblk2 = mfast ? pos % MB2 : wsel % MB2, stem = mfast ? pos / (MB2 * upw) : wsel / MB2, unit0 = (mfast ? (pos / MB2) % upw : pos % upw) * tpw;
     const int m0 = mblk2 * 32;
     if (tid < 32) {                                                          // (visible after the first barrier of the K stream)
         const size_t ci = stem * p.coeff_stem + m0 + tid;
@@ -649,7 +650,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         };
         // K step k: U slab k in buffer su (= k % UR), patch k+1 in slot sp1; issues U slab k+D -> buffer sd and patch k+1+D -> slot sd1
         float4 a0[2], a1[2];                                                 // A operands of the next two quads (EA: carried across K steps)
-        auto kstep = [&](int k, int su, int sp1, int sd, int sd1) __attribute__((always_inline)) {
+        auto kstep = [&](int k, int su, int sp1, int sd, int sd1, auto fc) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(fc)::value;                      // first K step of a unit: C = 0 (wino_c)
             // past the end of the unit: CS - the first slabs / patches of the workgroup's next unit (U does not depend on the unit; after the last unit the
             // "next" state equals the current one: valid addresses, unused data); otherwise the last slab / patch again, unused
             // (the DMA state - c_* - switches to the next unit at the first step whose patch belongs to it: a 4-way select between the two
@@ -687,10 +689,10 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], acc[mb][4 * q], 0, 0, 0);
-                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], acc[mb][4 * q + 1], 0, 0, 0);
-                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], acc[mb][4 * q + 2], 0, 0, 0);
-                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], acc[mb][4 * q + 3], 0, 0, 0);
+                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], wino_c<FIRST>(acc[mb][4 * q]), 0, 0, 0);
+                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], wino_c<FIRST>(acc[mb][4 * q + 1]), 0, 0, 0);
+                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], wino_c<FIRST>(acc[mb][4 * q + 2]), 0, 0, 0);
+                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], wino_c<FIRST>(acc[mb][4 * q + 3]), 0, 0, 0);
                 }
                 // one VALU instruction between two MFMAs of a wave costs about twice what it costs inside a burst (scripts/ubench/mfma_valu.hip:
                 // +26 % against +13 % at one VALU per MFMA): keep the quad's vector work behind its eight MFMAs instead of letting the
@@ -722,12 +724,15 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         if (CS && tpw > 1) unit_nxt(unit0 + 1); else unit_nxt_is_cur();
         issue_first();
         int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;           // k % UR, (k+1) % UR, (k+D) % UR, (k+1+D) % UR  (CS: of the running step count)
+        auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int x = 0; x < NP; ++x)
+                for (int x = 0; x < NP; ++x)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+        };
+        if constexpr (!PEEL) zero_acc();
         auto unit_prologue = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
             __syncthreads();
@@ -742,16 +747,20 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         if (CS) unit_prologue();
         for (int t = 0; t < tpw; ++t) {
         if (!CS) unit_prologue();
-        for (int k = 0; k < nk; k += BPS) {
+        // (the first group of K steps is peeled: its first step starts the unit's accumulators from C = 0)
+        auto kgroup = [&](int k, auto fc) __attribute__((always_inline)) {
             // vmcnt((D-BPS) DPW): everything older than the pieces of this wave's last D-BPS steps has landed: U slabs up to k+BPS-1 and patches up
             // to k+BPS (issued in step k+BPS-1-D).  After the barrier so have everyone's, and every wave has finished step k-1.
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - BPS - EA) * DPW)); __syncthreads(); }
 #pragma unroll
             for (int b = 0; b < BPS; ++b) {
-                if (BPS == 1 || k + b < nk) kstep(k + b, su, sp1, sd, sd1);
+                if (b == 0) kstep(k, su, sp1, sd, sd1, fc);
+                else if (k + b < nk) kstep(k + b, su, sp1, sd, sd1, std::false_type{});
                 su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
             }
-        }
+        };
+        if constexpr (PEEL) { kgroup(0, std::true_type{}); for (int k = BPS; k < nk; k += BPS) kgroup(k, std::false_type{}); }
+        else for (int k = 0; k < nk; k += BPS) kgroup(k, std::false_type{});
         if (!CS && t + 1 < tpw) {
             __syncthreads();
             unit_cur(unit0 + t + 1);
@@ -789,12 +798,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
             else emit([&](float y, float b, float s, float f) { return srt_dec_epilogue_lin(y, b, s, f, actp.lin); });
         }
         if (t + 1 < tpw) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int x = 0; x < NP; ++x)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+            if constexpr (!PEEL) zero_acc();
             if (CS && t + 2 < tpw) unit_nxt(unit0 + t + 2);                  // (the DMA state itself moved on D+1 steps before the unit ended; after the last unit it keeps valid addresses)
         }
         }                                                                    // units
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 //   * the four classes ADD into the same 2 x 2 outputs, and they live in four different waves: at the end of a unit the waves exchange their
 //     classes' outputs through LDS (24 KiB per M block; the second M block borrows the U ring slot the unit has just finished with) and each
 //     lane finishes one of its four channels (+ bias -> raw, and act(BN(.)) -> the copy for the next layer): two barriers per unit.
-template <int BA, int BB, int NI, int ABL = 0>
+template <int BA, int BB, int NI, int ABL = 0, int PEEL = 0>                 // PEEL: as srt_dec_wino32
 __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 32 && (BA * BB) % 16 == 0, "tile");
@@ -845,11 +849,12 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int MB2 = p.Cout / 32, MB = p.Cout / 16;
     const int walk = (tpw >> 9) & 1;                                         // column walk (wino_sp_xy)
+    const bool mfast = ((tpw >> 10) & 1) != 0;                               // M-block pair fastest in the launch order (see srt_dec_wino32)
     tpw &= 255;
     const int colrun = !walk ? 1 : tilesY % tpw == 0 ? tpw : tpw % tilesY == 0 ? tilesY : 1;
     const int nsp = tilesX * tilesY, groups = (p.ntiles + NI - 1) / NI, upw = nsp * groups / tpw;
     const int pos = srt_xcd_order(upw * MB2 * p.nstems);
-    const int wsel = pos / upw, mblk2 = wsel % MB2, stem = wsel / MB2, unit0 = (pos % upw) * tpw;
+    const int wsel = pos / upw, mblk2 = mfast ? pos % MB2 : wsel % MB2, stem = mfast ? pos / (MB2 * upw) : wsel / MB2, unit0 = (mfast ? (pos / MB2) % upw : pos % upw) * tpw;
     const int m0 = mblk2 * 32;
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
@@ -875,7 +880,7 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     unsigned c_flo, c_fhi, c_plo, c_phi, c_fvoff, c_pvoff, n_flo, n_fhi, n_plo, n_phi, n_fvoff, n_pvoff;      // DMA state of the current / next unit
     struct UnitBase { unsigned flo, fhi, plo, phi; };
     auto unit_base = [&](int unit) {
-        const int tile0 = (unit / nsp) * NI;
+        const int tile0 = ABL == 10 ? 0 : (unit / nsp) * NI;
         const size_t bi_ = (size_t)(p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile), bu_ = (size_t)up;
         UnitBase u;
         u.plo = __builtin_amdgcn_readfirstlane((unsigned)bi_); u.phi = __builtin_amdgcn_readfirstlane((unsigned)(bi_ >> 32));
@@ -884,6 +889,7 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     };
     // patch float4 e = ((c * NI + ii) * PH + row) * PR4 + j  <-  channel 4k+c, instance tile0+ii, input row 4 ty0 - 1 + row, columns 4 tx0 - 4 + 4j .. +3
     auto patch_voff = [&](int unit, int piece) {
+        if (ABL == 10) unit = 0;                                             // (tuning builds: every patch from one place - L2 hits - to see what the patch traffic costs)
         int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
         const int tile0 = (unit / nsp) * NI, tx0 = sx_ * BB, ty0 = sy_ * BA;     // tile origin in BLOCKS
         const int e = piece * 64 + lane;
@@ -965,7 +971,8 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
                 for (int i = 0; i < DPW; ++i) dma(i, min(j, nk - 1), j, min(j, nk - 1), j);
         };
         float4 a0[2], a1[2];
-        auto kstep = [&](int k, int su, int sp1, int sd, int sd1) __attribute__((always_inline)) {
+        auto kstep = [&](int k, int su, int sp1, int sd, int sd1, auto fc) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(fc)::value;                      // first K step of a unit: C = 0 (wino_c)
             if (k + 1 + D == nk) unit_advance();                             // the DMA state moves to the next unit with the first patch that belongs to it
             const int kd = k + D >= nk ? k + D - nk : k + D, kp = k + 1 + D >= nk ? k + 1 + D - nk : k + 1 + D;
             const float* ub = s_u + su * UBUF + aoff + X0;
@@ -992,10 +999,10 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], acc[mb][4 * q], 0, 0, 0);
-                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], acc[mb][4 * q + 1], 0, 0, 0);
-                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], acc[mb][4 * q + 2], 0, 0, 0);
-                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], acc[mb][4 * q + 3], 0, 0, 0);
+                    acc[mb][4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, v[4 * q], wino_c<FIRST>(acc[mb][4 * q]), 0, 0, 0);
+                    if constexpr (nm > 1) acc[mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, v[4 * q + 1], wino_c<FIRST>(acc[mb][4 * q + 1]), 0, 0, 0);
+                    if constexpr (nm > 2) acc[mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, v[4 * q + 2], wino_c<FIRST>(acc[mb][4 * q + 2]), 0, 0, 0);
+                    if constexpr (nm > 3) acc[mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, v[4 * q + 3], wino_c<FIRST>(acc[mb][4 * q + 3]), 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);                           // the quad's vector work stays behind its eight MFMAs
                 if constexpr (ABL != 4) {
@@ -1023,12 +1030,14 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         unit_cur(unit0);
         if (tpw > 1) unit_nxt(unit0 + 1); else unit_nxt_is_cur();
         issue_first();
+        if constexpr (!PEEL) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int x = 0; x < NP; ++x)
+                for (int x = 0; x < NP; ++x)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
         __syncthreads();
 #pragma unroll
@@ -1047,10 +1056,15 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
             ebias[mb] = p.bias[ci]; esc[mb] = p.outAct ? p.bnScale[ci] : 0.0f; esf[mb] = p.outAct ? p.bnShift[ci] : 0.0f;
         }
         for (int t = 0; t < tpw; ++t) {
-        for (int k = 0; k < nk; ++k) {
+        if constexpr (PEEL) {                                                // (the unit's accumulators start from C = 0: no zeroing pass)
+            if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - 1) * DPW)); __syncthreads(); }
+            kstep(0, su, sp1, sd, sd1, std::true_type{});
+            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
+        }
+        for (int k = PEEL ? 1 : 0; k < nk; ++k) {
             // vmcnt: everything older than this wave's last step of pieces has landed (U slab k, patch k+1); the prologue's extra patch pieces are older still
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - 1) * DPW)); __syncthreads(); }
-            kstep(k, su, sp1, sd, sd1);
+            kstep(k, su, sp1, sd, sd1, std::false_type{});
             su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
         }
         // ---- unit epilogue: the four classes' 2 x 2 outputs of a (channel, block) live in four waves and meet in LDS.  Lane (kq, l15) of the class-c
@@ -1122,12 +1136,14 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
             finish(1, x1);
         }
         if (t + 1 < tpw) {
+            if constexpr (!PEEL) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int x = 0; x < NP; ++x)
+                    for (int x = 0; x < NP; ++x)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+                        for (int r = 0; r < 4; ++r) acc[mb][x][r] = 0.0f;
+            }
             if (t + 2 < tpw) unit_nxt(unit0 + t + 2);
         }
         }                                                                    // units
@@ -1192,6 +1208,21 @@ static int wino_walk_bit()
 #endif
     return SRT_WINO_WALK_DEFAULT ? 512 : 0;
 }
+// bit 10 of the kernels' tpw argument: the M-block pair is the fastest index of the launch order (srt_dec_wino32 / srt_enc_wino32) for layers whose
+// transformed weights are small enough for all pairs of a stem to share an XCD's L2 (4 MiB) beside the patches: `ubytes` per stem at most 2 MiB.
+// SRT_TUNE=winomf=0|1 forces it off / on in tuning builds.
+#ifndef SRT_WINO_MFAST_DEFAULT
+#define SRT_WINO_MFAST_DEFAULT 0
+#endif
+static int wino_mfast_bit(size_t ubytes, int mb2)
+{
+    if (mb2 < 2) return 0;
+#ifdef SRT_TUNING
+    const int v = wino_tune("winomf=");
+    if (v >= 0) return v ? 1024 : 0;
+#endif
+    return SRT_WINO_MFAST_DEFAULT && ubytes <= ((size_t)2 << 20) ? 1024 : 0;
+}
 // Layers with a multiple of 32 output channels (up2..up4) run the 32-channel workgroup, srt_dec_wino32, in the arrangement measured
 // fastest at 64 tiles x 4 stems: rings of three, fenced VALU bursts, staggered wave pairs, the units of a
 // workgroup as one continuous K stream.  SRT_TUNE=wino32=0|1 and winocfg=<n> select the other measured arrangements in tuning builds.
@@ -1242,9 +1273,10 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 8: W32(0, 5, 3, 2, 1, 0, 1, 1);                                 // rings of 5, barrier per two steps, continuous K stream across units
         case 10: W32(0, 5, 3, 2, 1, 0, 1, 0);                                // the same without the continuous stream
         }
+        if (wino_tune("winopeel=") == 1) W32(0, 3, 2, 1, 1, 0, 1, 1, 1, 1);            // the shipped arrangement with the first K step peeled (C = 0)
 #undef W32
 #endif
-        SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
+        SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32));
         return srt_launch_status();
     }
     if (p.H >= 8 && p.W >= 32) {
@@ -1319,9 +1351,11 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 7: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 7>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         case 8: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 8>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         case 9: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 9>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
+        case 10: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 10>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         }
+        if (wino_tune("winopeel=") == 1) { SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
 #endif
-        SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit());
+        SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32));
     } else if (Ho >= 4 && Wo >= 16) {
         const long units = (long)((Wo + 15) / 16) * ((Ho + 3) / 4) * ((p.ntiles + 1) / 2), wgs = units * (p.Cout / 32) * p.nstems;
         const int tpw = wino_tpw(wgs, units);
