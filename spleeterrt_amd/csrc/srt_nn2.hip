@@ -438,7 +438,8 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
 // 8 c .. 8 c + 7 = 9 DMA pieces.  Interval i reads rows 8 i - 1 .. 8 i + 9: chunks i - 1 (its last row), i, i + 1 while chunk i + 2 lands.
 #define SRT_D1S_PITCH 144
 typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
-template <int ABL = 0>                                                          // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
+// H16 (fp16 activation storage, srt_config.precision F16): conv + bias AND act(BN(.)) leave as halves, two 8-byte stores per channel row (see srt_enc_mfma2, twoOut)
+template <int ABL = 0, bool H16 = false>                                        // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
 __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvParams p)
 {
     constexpr int PITCH = SRT_D1S_PITCH, RING = 32, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64;      // 576 float4 = 9 pieces per chunk
@@ -456,17 +457,23 @@ __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvP
     for (int tap = 0; tap < 25; ++tap) a[tap] = p.wpack2[(size_t)(half * 25 + tap) * p.CP2 + mt * 32 + l31];
     // output rows of this lane's 16 accumulator registers: stacked row m = 32 mt + (r & 3) + 8 (r >> 2) + 4 half -> (stem, channel)
     float bi[16]; unsigned ob[16];
+    float sc2[H16 ? 16 : 1], sf2[H16 ? 16 : 1];
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1), st = m >> 4, co = m & 15;
         bi[r] = p.bias[st * p.coeff_stem + co];
+        if constexpr (H16) { sc2[r] = p.bnScale[st * p.coeff_stem + co]; sf2[r] = p.bnShift[st * p.coeff_stem + co]; }
         ob[r] = (unsigned)(st * p.out_stem + (size_t)co * ohw);                 // (the launcher checks that the output tensor has fewer than 2^32 elements)
     }
+    // activation of each 16-row stem group (registers 0..7 / 8..15)
+    const int stg0 = min(2 * mt, p.stack - 1), stg1 = min(2 * mt + 1, p.stack - 1);
+    const SrtAct apg[2] = { srt_act_params(((p.elu_mask >> stg0) & 1u) ? SRT_ACT_ELU : p.act, p.variant), srt_act_params(((p.elu_mask >> stg1) & 1u) ? SRT_ACT_ELU : p.act, p.variant) };
     const bool ok_lo = mt * 32 < mlimit, ok_hi = mt * 32 + 16 < mlimit;         // wave-uniform: registers 0..7 are one stem's channels, 8..15 the next stem's
-    const int nst = ABL == 1 ? 0 : (ok_lo ? 8 : 0) + (ok_hi ? 8 : 0);          // stores this wave issues per interval
+    const int nst = ABL == 1 ? 0 : ((ok_lo ? 8 : 0) + (ok_hi ? 8 : 0)) * (H16 ? 2 : 1);          // stores this wave issues per interval
     const int oyl = 2 * reg + (l31 >> 4), oxl = 4 * (l31 & 15);
-    float* outp = p.outRaw + (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl;
+    const size_t pix0 = (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl;
+    float* outp = p.outRaw + pix0;
     // ---- DMA: float4 e = piece * 64 + lane of a chunk = (row * 2 + ch) * 36 + j  <-  channel ch, image row 8 c + row, columns 2 ox0 - 4 + 4 j .. + 3
     constexpr unsigned OOR = 0x80000000u;
     const size_t hw = (size_t)p.H * p.W;
@@ -501,7 +508,8 @@ __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvP
     const int nint = Ho / 4;
     for (int i = 0; i < nint; ++i) {
         // my pieces of chunk i + 1 (issued during interval i - 1, before its 16 stores) have landed; the stores may still be in flight
-        if (nst == 16) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));      // vmcnt(16)
+        if (nst == 32) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));      // vmcnt(32)
+        else if (nst == 16) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14)); // vmcnt(16)
         else if (nst == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();                                                        // everyone's pieces; everyone is done with chunk i - 2 (the slot chunk i + 2 lands in)
@@ -532,7 +540,16 @@ __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvP
                 if (r < 8 ? ok_lo : ok_hi) {
                     float4 v;
                     v.x = acc[0][r] + bi[r]; v.y = acc[1][r] + bi[r]; v.z = acc[2][r] + bi[r]; v.w = acc[3][r] + bi[r];
-                    *reinterpret_cast<float4*>(orow + ob[r]) = v;
+                    if constexpr (H16) {
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        const size_t eo = pix0 + (size_t)(4 * i) * Wo + ob[r];
+                        h4 hv, ha;
+                        hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+                        ha[0] = (_Float16)srt_enc_epilogue(v.x, sc2[r], sf2[r], apg[r >> 3]); ha[1] = (_Float16)srt_enc_epilogue(v.y, sc2[r], sf2[r], apg[r >> 3]);
+                        ha[2] = (_Float16)srt_enc_epilogue(v.z, sc2[r], sf2[r], apg[r >> 3]); ha[3] = (_Float16)srt_enc_epilogue(v.w, sc2[r], sf2[r], apg[r >> 3]);
+                        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.outRaw) + eo) = hv;
+                        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.outAct) + eo) = ha;
+                    } else *reinterpret_cast<float4*>(orow + ob[r]) = v;
                 }
             }
         }
@@ -1066,14 +1083,16 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 #ifdef SRT_TUNING
             if (getenv("SRT_TUNE") && strstr(getenv("SRT_TUNE"), "d1s=")) streamed = tune("d1s");      // d1s=0 tiled kernel, 2 / 3: ablations
 #endif
-            if (streamed && p.stack * p.Cout <= 64 && p.CP2 >= 64 && !p.out16 && !p.ws && Wo % 64 == 0 && Ho % 4 == 0 && (long)(Wo / 64) * p.ntiles >= 384 &&
+            const bool h16 = p.out16 && p.outAct && p.bnScale && p.bnShift;   // fp16 storage: raw + act(BN(.)) as halves
+            if (streamed && p.stack * p.Cout <= 64 && p.CP2 >= 64 && (!p.out16 || h16) && !p.ws && Wo % 64 == 0 && Ho % 4 == 0 && (long)(Wo / 64) * p.ntiles >= 384 &&
                 (size_t)p.stack * p.out_stem < ((size_t)1 << 32) && (size_t)8 * p.H * p.W < 0x7fffffffu) {
                 const dim3 grid((unsigned)((Wo / 64) * p.ntiles));
 #ifdef SRT_TUNING
                 if (streamed == 2) { SRT_LAUNCH((srt_down1_stream_kernel<1>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
                 if (streamed == 3) { SRT_LAUNCH((srt_down1_stream_kernel<2>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
 #endif
-                SRT_LAUNCH((srt_down1_stream_kernel<0>), grid, dim3(256), 0, s, p);
+                if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true>), grid, dim3(256), 0, s, p);
+                else SRT_LAUNCH((srt_down1_stream_kernel<0>), grid, dim3(256), 0, s, p);
                 return srt_launch_status();
             }
         }

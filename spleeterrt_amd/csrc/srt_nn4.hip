@@ -954,10 +954,15 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         f32x4 acc[2][NP];
         float t3[4][4], t2[4][3];
         float xr[4][4];                                                      // patch row r of the class: its plane's 4 (3) pixels
+        // a block's columns are 4 floats apart for every lane and the channel pitch is a multiple of 4 floats (16-byte DMA pieces), so a ds_read_b32 of the
+        // wave touches 16 of the 64 banks: a 4-way conflict, as long in the LDS pipe as a conflict-free ds_read_b128.  The middle pair of a row therefore
+        // comes from ONE aligned b128 (columns 4xb .. 4xb+3: the odd plane takes .y / .w, the even plane .x / .z) and only the outer one or two values
+        // are single reads: 3 (2) LDS instructions per row instead of 4 (3), half the conflicted ones.
         auto read_row = [&](const float* pbuf, int r) {
-            const float* q = pbuf + poff + (Y3 ? 2 * r : 2 * r + 1) * PROW + (X3 ? 0 : 1);
-            xr[r][0] = q[0]; xr[r][1] = q[2]; xr[r][2] = q[4];
-            if constexpr (X3) xr[r][3] = q[6];
+            const float* b = pbuf + poff - 3 + (Y3 ? 2 * r : 2 * r + 1) * PROW;      // input column 4xb - 4: 16-byte aligned
+            const float4 m = *reinterpret_cast<const float4*>(b + 4);
+            if constexpr (X3) { xr[r][0] = b[3]; xr[r][1] = m.y; xr[r][2] = m.w; xr[r][3] = b[9]; }
+            else { xr[r][0] = m.x; xr[r][1] = m.z; xr[r][2] = b[8]; }
         };
         auto rows = [&](int r) {
             if constexpr (X3) wino_in3(xr[r][0], xr[r][1], xr[r][2], xr[r][3], t3[r]);
