@@ -797,22 +797,27 @@ __global__ void __launch_bounds__(256, OCC) srt_up6_kernel(const SrtConvParams p
 // the neighbour column's lines, read by the neighbouring workgroup at the same time on the same XCD.  Sums in the order of the kernel above
 // (channels ascending in the MFMA chain, taps ascending in the gather): bit-identical results.
 typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
-template <int TW, int CR, int ABL = 0>                                      // ABL (tuning builds, wrong results): 1 no DMA, 2 DMA only, 3 no gather
+// H16 (fp16 activation storage): the two source tensors hold halves - 16-byte DMA pieces are 8 pixels, a patch row is tx0 - 8 .. tx0 + 71 - and the
+// contraction is the tiled fp16 kernel's (srt_up6_kernel<.., true>: two v_mfma_f32_32x32x16_f16 per 32 pixels, weights rounded to fp16, the same
+// operands in the same order): bit-identical to it, half the input bytes.
+template <int TW, int CR, int ABL = 0, bool H16 = false>                    // ABL (tuning builds, wrong results): 1 no DMA, 2 DMA only, 3 no gather
 __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvParams p)
 {
     constexpr int CIN = 32, CAH = 16;
-    constexpr int PW = TW + 2, SEG = TW / 4 + 2, PROW = SEG * 4;             // pixels of a chunk row incl. halo; float4 segments per row (from tx0 - 4)
+    constexpr int EPP = H16 ? 8 : 4, ESZ = H16 ? 2 : 4, LEAD = EPP - 1;      // elements per 16-byte DMA piece; bytes per element; patch column of pixel tx0 - 1
+    constexpr int PW = TW + 2, SEG = TW / EPP + 2, PROW = SEG * EPP;         // pixels of a chunk row incl. halo; 16-byte segments per row (from tx0 - EPP)
     constexpr int CHF4 = CR * SEG, NF4 = CIN * CHF4, NPIECE = NF4 / 64, NWAVE = 8, NDW = 4, PPW = (NPIECE + NDW - 1) / NDW;
     static_assert(NF4 % 64 == 0 && (CAH * CHF4) % 64 == 0, "a DMA piece (64 lanes x 16 B) must not straddle the two source tensors");
     static_assert(TW == 64 && 2 * CR <= NWAVE, "gather: a wave per (row of the chunk, output row parity), a lane per pixel");
-    constexpr int PBUF = CIN * CR * PROW;
+    constexpr int PBUF = CIN * CR * PROW;                                     // elements
+    constexpr int PBUF_F = PBUF * ESZ / 4;                                    // ... in floats of the LDS array
     constexpr int RR = 2 * CR + 2, RWP = 72;                                  // ring rows; row pitch of a tap plane (4 * RWP = 32 mod 64 banks: the two lane halves write disjoint banks)
     static_assert(RWP >= PW, "ring pitch");
     constexpr int NPIX = CR * PW, NG = (NPIX + 31) / 32;
     static_assert(NG <= NWAVE && 2 * CR == NWAVE - NDW, "one pixel group per wave; waves NDW.. gather");
-    __shared__ __attribute__((aligned(16))) float s_all[2 * PBUF + RR * 25 * RWP];
+    __shared__ __attribute__((aligned(16))) float s_all[2 * PBUF_F + RR * 25 * RWP];
     float* s_p = s_all;
-    float* s_r = s_all + 2 * PBUF;
+    float* s_r = s_all + 2 * PBUF_F;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesX = (p.W + TW - 1) / TW;
@@ -821,11 +826,22 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const float* w = p.wraw + stem * p.coeff_stem;                            // [Cin][1][25]
-    float a[CIN / 2];
+    float a[H16 ? 1 : CIN / 2];
+    srt_h8 a16[H16 ? 2 : 1];
+    if constexpr (H16) {
 #pragma unroll
-    for (int cp = 0; cp < CIN / 2; ++cp) {
-        const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
-        a[cp] = l31 < 25 ? v : 0.0f;
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = w[(kg * 16 + half * 8 + q) * 25 + min(l31, 24)];
+                a16[kg][q] = (_Float16)(l31 < 25 ? v : 0.0f);
+            }
+    } else {
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) {
+            const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
+            a[cp] = l31 < 25 ? v : 0.0f;
+        }
     }
     // ---- DMA: float4 e = (ch * CR + row) * SEG + j of a chunk <- channel ch, image row CR i + row, columns tx0 - 4 + 4 j .. + 3; wave w moves pieces w, w + 4, ...
     constexpr unsigned OOR = 0x80000000u;
@@ -833,18 +849,18 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int piece = min(wave + NDW * q, NPIECE - 1), e = piece * 64 + lane;
-        const int j = e % SEG, row = (e / SEG) % CR, chl = (e / CHF4) % CAH, gx = tx0 - 4 + 4 * j;
+        const int j = e % SEG, row = (e / SEG) % CR, chl = (e / CHF4) % CAH, gx = tx0 - EPP + EPP * j;
         prow[q] = row;
-        c0[q] = (gx >= 0 && gx + 3 < p.W) ? 4u * (unsigned)((size_t)chl * hw + (size_t)row * p.W + gx) : OOR;
+        c0[q] = (gx >= 0 && gx + EPP - 1 < p.W) ? (unsigned)ESZ * (unsigned)((size_t)chl * hw + (size_t)row * p.W + gx) : OOR;
     }
-    const size_t ba_ = (size_t)(p.srcA + stem * p.srcA_stem + tile * p.srcA_tile), bb_ = (size_t)(p.srcB + stem * p.srcB_stem + tile * p.srcB_tile);
+    const size_t ba_ = (size_t)p.srcA + (size_t)ESZ * (stem * p.srcA_stem + tile * p.srcA_tile), bb_ = (size_t)p.srcB + (size_t)ESZ * (stem * p.srcB_stem + tile * p.srcB_tile);
     srt_i32x4 rsA, rsB;
     rsA.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba_); rsA.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba_ >> 32) & 0xffffu));
     rsB.x = __builtin_amdgcn_readfirstlane((int)(unsigned)bb_); rsB.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(bb_ >> 32) & 0xffffu));
-    rsA.z = rsB.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)4 * CAH * hw); rsA.w = rsB.w = 0x00020000;
+    rsA.z = rsB.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)ESZ * CAH * hw); rsA.w = rsB.w = 0x00020000;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
     auto dma_chunk = [&](int i) {
-        const unsigned adv = 4u * (unsigned)(i * CR * p.W), base = lds0 + (unsigned)((i & 1) * PBUF * 4);
+        const unsigned adv = (unsigned)ESZ * (unsigned)(i * CR * p.W), base = lds0 + (unsigned)((i & 1) * PBUF * ESZ);
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
             const int piece = min(wave + NDW * q, NPIECE - 1);                // wave-uniform (a piece past the last one repeats it)
@@ -868,15 +884,27 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
         const int grp = wave < NDW ? wave : NDW + ((wave - i) & (NWAVE - NDW - 1));   // groups NDW.. go round the gather waves (one SIMD each) interval by interval
         if (ABL != 2 && i < nchunks && grp < NG) {                            // wave-uniform
             const int pix = min(grp * 32 + l31, NPIX - 1), row = pix / PW, col = pix % PW;
-            const float* bsrc = s_p + (i & 1) * PBUF + (half * CR + row) * PROW + col + 3;
-            float b[CIN / 2];
-#pragma unroll
-            for (int cp = 0; cp < CIN / 2; ++cp) b[cp] = bsrc[cp * 2 * CR * PROW];
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if constexpr (H16) {
+                // k-group kg = channels 16 kg .. 16 kg + 15; lane half holds 8 of them for its pixel (channel-major rows in LDS: 8 single reads)
+                const _Float16* bsrc = reinterpret_cast<const _Float16*>(s_p) + (i & 1) * PBUF + (half * 8 * CR + row) * PROW + col + LEAD;
+                srt_h8 b16[2];
 #pragma unroll
-            for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+                for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) b16[kg][q] = bsrc[(kg * 16 + q) * CR * PROW];
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[kg], b16[kg], acc, 0, 0, 0);
+            } else {
+                const float* bsrc = s_p + (i & 1) * PBUF + (half * CR + row) * PROW + col + LEAD;
+                float b[CIN / 2];
+#pragma unroll
+                for (int cp = 0; cp < CIN / 2; ++cp) b[cp] = bsrc[cp * 2 * CR * PROW];
+#pragma unroll
+                for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+            }
             int slot = slot0 + row; slot = slot >= RR ? slot - RR : slot;
             if (grp * 32 + l31 < NPIX) {
 #pragma unroll
@@ -974,8 +1002,9 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 #endif
         // fp32 tensors, batches that fill the chip with column workgroups (2 per CU): the streamed form
         const long cols = (long)((p.W + 63) / 64) * p.nstems * p.ntiles;
-        if (!p.in16 && p.CA == 16 && p.W % 4 == 0 && p.srcA && p.srcB && (size_t)64 * p.H * p.W < 0x7fffffffu && ((cols >= 512 && v == 0 && SRT_UP6_STREAM_DEFAULT) || v == 11)) {
-            SRT_LAUNCH((srt_up6_stream_kernel<64, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);
+        if (p.CA == 16 && p.W % (p.in16 ? 8 : 4) == 0 && p.srcA && p.srcB && (size_t)64 * p.H * p.W < 0x7fffffffu && ((cols >= 512 && v == 0 && SRT_UP6_STREAM_DEFAULT) || v == 11)) {
+            if (p.in16) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 0, true>), dim3((unsigned)cols), dim3(512), 0, s, p);       // halves in, fp32 out (fp16 activation storage)
+            else SRT_LAUNCH((srt_up6_stream_kernel<64, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);
             return srt_launch_status();
         }
 #ifdef SRT_TUNING

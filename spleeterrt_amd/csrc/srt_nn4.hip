@@ -823,11 +823,12 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 //   * the four classes ADD into the same 2 x 2 outputs, and they live in four different waves: at the end of a unit the waves exchange their
 //     classes' outputs through LDS (24 KiB per M block; the second M block borrows the U ring slot the unit has just finished with) and each
 //     lane finishes one of its four channels (+ bias -> raw, and act(BN(.)) -> the copy for the next layer): two barriers per unit.
-template <int BA, int BB, int NI, int ABL = 0, int PEEL = 0>                 // PEEL: as srt_dec_wino32
+template <int BA, int BB, int NI, int ABL = 0, int PEEL = 0, int PR = 3>     // PEEL: as srt_dec_wino32.  PR: depth of the PATCH ring (patches PR - 1 K steps ahead; the U slabs stay two ahead in a ring of three)
 __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 32 && (BA * BB) % 16 == 0, "tile");
-    constexpr int UR = 3, D = 2;                                             // rings of three, slabs two K steps ahead, one barrier per K step
+    constexpr int UR = 3, D = 2, PD = PR - 1;                                // U ring of three, slabs two K steps ahead, one barrier per K step; patches PD steps ahead
+    static_assert(PR >= 3 && PR <= 4, "patch ring");
     constexpr int UB1 = 4 * 16 * WINO_LD, UBUF = 2 * UB1, NUP = 26;
     constexpr int TH = 2 * BA, TW = 2 * BB;                                  // OUTPUT pixels per instance
     constexpr int PH = 4 * BA + 3, PROW = 4 * BB + 8, PR4 = PROW / 4;        // input patch
@@ -836,10 +837,10 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     static_assert(DPW == 5 && NPP >= 7 && NPP <= 14, "piece map: per wave three U pieces, one U-or-patch piece, one patch piece");
     constexpr int XBUF = 4 * 2 * 4 * 3 * 16 * 4;                             // class exchange of one M block: [writer class][group][kq][3 published channels][block][2 x 2 outputs] = 24 KiB
     static_assert(XBUF <= UBUF, "the second M block's exchange lives in a U ring slot");
-    __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF + XBUF];
+    __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + PR * PBUF + XBUF];
     float* s_u = s_all;
     float* s_p = s_all + UR * UBUF;
-    float* s_x = s_all + UR * UBUF + UR * PBUF;
+    float* s_x = s_all + UR * UBUF + PR * PBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -974,12 +975,17 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
             for (int j = 0; j < D; ++j)
 #pragma unroll
                 for (int i = 0; i < DPW; ++i) dma(i, min(j, nk - 1), j, min(j, nk - 1), j);
+#pragma unroll
+            for (int j = D; j < PD; ++j) {                                   // deeper patch ring: the patches between the slab lead and the patch lead
+                if (flex_patch) dma_flex(0, 0, min(j, nk - 1), j);
+                dma_patch(min(j, nk - 1), j);
+            }
         };
         float4 a0[2], a1[2];
         auto kstep = [&](int k, int su, int sp1, int sd, int sd1, auto fc) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(fc)::value;                      // first K step of a unit: C = 0 (wino_c)
-            if (k + 1 + D == nk) unit_advance();                             // the DMA state moves to the next unit with the first patch that belongs to it
-            const int kd = k + D >= nk ? k + D - nk : k + D, kp = k + 1 + D >= nk ? k + 1 + D - nk : k + 1 + D;
+            if (k + 1 + PD == nk) unit_advance();                            // the DMA state moves to the next unit with the first patch that belongs to it
+            const int kd = k + D >= nk ? k + D - nk : k + D, kp = k + 1 + PD >= nk ? k + 1 + PD - nk : k + 1 + PD;
             const float* ub = s_u + su * UBUF + aoff + X0;
             const float* pbuf = s_p + sp1 * PBUF;
 #pragma unroll
@@ -1049,9 +1055,9 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         for (int r = 0; r < NROW; ++r) { read_row(s_p, r); rows(r); }
         WinoFor<0, NP>::run([&](auto xc) { constexpr int x = decltype(xc)::value; v[x] = wino_point<X0 + x>(t3, t2); });
         // patch D -> slot D: the wave's patch pieces only (its U pieces of this round went out above); from here on exactly DPW DMA instructions per step
-        if (flex_patch) dma_flex(0, 0, min(D, nk - 1), D % UR);
-        dma_patch(min(D, nk - 1), D % UR);
-        int su = 0, sp1 = 1 % UR, sd = D % UR, sd1 = (D + 1) % UR;
+        if (flex_patch) dma_flex(0, 0, min(PD, nk - 1), PD % PR);
+        dma_patch(min(PD, nk - 1), PD % PR);
+        int su = 0, sp1 = 1 % PR, sd = D % UR, sd1 = (PD + 1) % PR;
         // epilogue constants of this lane's two output channels, before the K stream: loaded in the epilogue they sat between its stores, and a wait
         // for a load also waits for every store issued before it (three store round trips per unit)
         float ebias[2], esc[2], esf[2];
@@ -1064,13 +1070,13 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         if constexpr (PEEL) {                                                // (the unit's accumulators start from C = 0: no zeroing pass)
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - 1) * DPW)); __syncthreads(); }
             kstep(0, su, sp1, sd, sd1, std::true_type{});
-            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
+            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == PR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == PR - 1 ? 0 : sd1 + 1;
         }
         for (int k = PEEL ? 1 : 0; k < nk; ++k) {
             // vmcnt: everything older than this wave's last step of pieces has landed (U slab k, patch k+1); the prologue's extra patch pieces are older still
             if (ABL != 1) { __builtin_amdgcn_s_waitcnt(wino_vmcnt((D - 1) * DPW)); __syncthreads(); }
             kstep(k, su, sp1, sd, sd1, std::false_type{});
-            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == UR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == UR - 1 ? 0 : sd1 + 1;
+            su = su == UR - 1 ? 0 : su + 1; sp1 = sp1 == PR - 1 ? 0 : sp1 + 1; sd = sd == UR - 1 ? 0 : sd + 1; sd1 = sd1 == PR - 1 ? 0 : sd1 + 1;
         }
         // ---- unit epilogue: the four classes' 2 x 2 outputs of a (channel, block) live in four waves and meet in LDS.  Lane (kq, l15) of the class-c
         // wave finishes channel 4 kq + c of each M block for its block: sum in the fixed order (C11 + C10) + (C01 + C00), + bias -> raw; act(BN(.)) ->
@@ -1359,6 +1365,7 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 10: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 10>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         }
         if (wino_tune("winopeel=") == 1) { SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
+        if (wino_tune("winopr=") == 4) { SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
 #endif
         SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32));
     } else if (Ho >= 4 && Wo >= 16) {

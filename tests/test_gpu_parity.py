@@ -193,6 +193,36 @@ def test_up6_streamed_form(oracle, coeffs, T, F, ntiles, stems):
     print("up6 streamed %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
 
 
+def test_up6_streamed_form_fp16_storage(oracle, coeffs):
+    """The streamed up6 on fp16 activation tensors (srt_up6_stream_kernel<.., H16>, round 4: 8-pixel DMA pieces, the tiled fp16 kernel's two
+    v_mfma_f32_32x32x16_f16 per 32 pixels): named by the engine at 33 tiles x 4 stems of 64 x 512, its output plane bit-identical to the tiled kernel's
+    on the same tile evaluated alone, and the masks of the batch inside the fp16 tolerance of BASELINE configs[4] against the fp32 oracle."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, stems, ntiles = 64, 512, 4, 33
+    modes = (1, 0, 1, 0)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, precision=srt.PREC_F16)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=1616)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    ks = _layer_kernels(eng, xd)
+    assert ks["up6"].startswith("srt_up6_stream_kernel<64, 2, 0, true"), ks["up6"]
+    planes = {(s, t): eng.tensor("up6", s, t) for s in (0, 3) for t in (0, 17, ntiles - 1)}
+    for (s, t), g in planes.items():
+        ref = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST)
+        assert np.abs(masks[s, t] - ref).max() <= 2e-2, (s, t, float(np.abs(masks[s, t] - ref).max()))
+    for t in (0, ntiles - 1):
+        one = torch.from_numpy(x[t:t + 1]).cuda()
+        eng.forward(one)
+        k1 = _layer_kernels(eng, one)
+        assert k1["up6"].startswith("srt_up6_kernel<"), k1["up6"]
+        for s in (0, 3):
+            assert np.array_equal(eng.tensor("up6", s, 0), planes[(s, t)]), (s, t)
+    eng.close()
+
+
 def test_forward_lut_variant(oracle, coeffs):
     import torch
     import spleeterrt_amd as srt
