@@ -2,6 +2,7 @@
 # One gpurun call of round 4:  bash scripts/gpu_r04.sh <tag> <stages...>
 #   tests    pytest -m gpu (whole suite)       newtests  only the tests added in round 4          bench   headline bench line
 #   prof     scripts/profile_gpu.sh            extras    f16 benches, c4 stream, latency script    quick   the short parity tests of the conv kernels
+#   proff16  scripts/profile_gpu_f16.sh (HBM counters of the fp16-storage mode)             benchq  short bench line without the CPU baseline
 set -u
 TAG=${1:-r04}; shift
 OUT=gpurun_out/$TAG
@@ -20,6 +21,7 @@ d = json.load(open("$OUT/benchq.json")); print("ms/step", round(d["ms_per_step"]
 PY
       tail -3 $OUT/bench.err ;;
     prof) timeout 900 bash scripts/profile_gpu.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
+    proff16) timeout 600 bash scripts/profile_gpu_f16.sh $TAG > $OUT/profile_f16.log 2>&1; tail -2 $OUT/profile_f16.log ;;
     extras)
       for prec in f16 f16x2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --precision $prec > $OUT/bench_$prec.json 2>> $OUT/bench.err; done
       timeout 300 python scripts/stream_c4.py --repeats 3 --out $OUT/c4.json > $OUT/c4.log 2>&1; tail -c 400 $OUT/c4.log
