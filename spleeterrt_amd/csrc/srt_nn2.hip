@@ -249,6 +249,11 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
         boff[nr] = half * CHS + (VECPIX ? 0 : il * INS) + 2 * oy * ROWS + ox;
     }
     const int aoff = half * 25 * BM + wm * MR * 32 + l31;
+    const __attribute__((address_space(3))) float* brow[NR][5];               // B-operand base per (sub-tile, kernel row): see the MFMA block
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) { brow[nr][ky] = (const __attribute__((address_space(3))) float*)(s_in + boff[nr] + ky * ROWS); asm volatile("" : "+v"(brow[nr][ky])); }
 
     // Epilogue constants go through LDS BEFORE the K loop.  Loaded from global memory at the start of the epilogue they put a
     // counted s_waitcnt vmcnt(n) in front of every output element, and since stores count in vmcnt too each of those waits also
@@ -302,6 +307,14 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
             if (ABL != 5) srt_dma_slab<WROWS, BM>(wp + (size_t)(ch + 1) * KC * 25 * CPW, CPW, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
             if (ABL != 4) load_patch((ch + 1) * KC);
         }
+        // operand addresses: the compiler pairs these dword reads into ds_read2_b32, whose two offsets are 8-bit dword counts, and derives a new base register
+        // (one v_add_u32) for every pair further than 1 KiB from the previous base: 22 VALU instructions per chunk of down2 beside its 50 fp32 MFMAs, each
+        // paid in matrix time.  One base per (sub-tile, kernel row) / per group of 8 taps, made opaque so that they are not folded back into one: the
+        // offsets that remain are a few hundred bytes and need no arithmetic.
+        typedef const __attribute__((address_space(3))) float* lds_cfp;
+        lds_cfp aq[(25 * (KC / 2) + 7) / 8];
+#pragma unroll
+        for (int gq = 0; gq < (25 * (KC / 2) + 7) / 8; ++gq) { aq[gq] = (lds_cfp)(sw + aoff + gq * 8 * BM); asm volatile("" : "+v"(aq[gq])); }
 #pragma unroll
         for (int cp = 0; cp < KC / 2; ++cp) {
 #pragma unroll
@@ -309,9 +322,9 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
                 const int ky = tap / 5, kx = tap % 5;
                 float a[MR], b[NR];
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[mr] = ABL == 3 ? (float)(tap + cp) : sw[aoff + (2 * cp * 25 + tap) * BM + mr * 32];
+                for (int mr = 0; mr < MR; ++mr) a[mr] = ABL == 3 ? (float)(tap + cp) : aq[(cp * 25 + tap) / 8][(2 * cp * 25 + tap - 8 * ((cp * 25 + tap) / 8)) * BM + mr * 32];
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) b[nr] = ABL == 3 ? (float)(nr + ch + tap) : s_in[boff[nr] + 2 * cp * CHS + ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)];
+                for (int nr = 0; nr < NR; ++nr) b[nr] = ABL == 3 ? (float)(nr + ch + tap) : brow[nr][ky][2 * cp * CHS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
