@@ -3,7 +3,8 @@
 # library on the same box:   bash scripts/gpu_tune.sh <tag> <f32|f16|f16x2> "SRT_TUNE=decx=20;SRT_TUNE=bm128=1;SRT_TUNE16=1;SRT_TUNE_HEAD=2"
 # Prints one line per setting: ms per 64-tile step and the per-layer kernel times (HIP events).  Keys: csrc/srt_nn2.hip (SRT_TUNE=key=value,...:
 # down1 down2 up4 up5 abl eabl encx decx bm128 occ3 dual), csrc/srt_nn4.hip (wino=<layer mask> winoforce=1 winotpw=<units per workgroup>
-# wino32=0|1 winocfg=1..10 winoabl=1..5 winoprio winoring winosb winocs winowalk=0|1 encwino=0|<min Cin> enccopy=0|1), csrc/srt_nn3.hip (SRT_TUNE16),
+# wino32=0|1 winocfg=1..10 winoabl=1..5 winoprio winoring winosb winocs winowalk=0|1 encwino=0|<min Cin> enccopy=0|1 encabl=1|3..10 winomf=0|1 winopeel=1
+# winopr=4; csrc/srt_nn2.hip also d1s=0|2|3), csrc/srt_nn3.hip (SRT_TUNE16),
 # csrc/srt_nn.hip (SRT_TUNE_UP6: 1-9 tile shapes of the old kernel, 10 old kernel, 11 streamed kernel forced, 12-14 its ablations; SRT_TUNE_HEAD,
 # SRT_TUNE_HEADROWS=0|2|4).
 set -u
