@@ -96,6 +96,23 @@ def test_c_partition_equals_rank_span():
     assert lib.srtRankSpan(4096, 64, 2, 2, C.byref(c)) < 0 and lib.srtRankSpan(4096, 64, 0, 0, C.byref(c)) < 0      # rank outside the world
 
 
+def test_multi_device_host_refuses_without_a_gpu():
+    """The native multi-device host has no CPU path either: without a HIP device srtMultiCreate fails with a code and a message (CPU suite only)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import spleeterrt_amd
+    from spleeterrt_amd.capi import _Config
+    lib = spleeterrt_amd.load_library()
+    cfg = _Config()
+    cfg.F, cfg.T, cfg.n_stems, cfg.max_tiles = 512, 64, 2, 2
+    h = C.c_void_p()
+    assert lib.srtDeviceCount() == 0
+    assert lib.srtMultiCreate(C.byref(cfg), None, 2, C.byref(h)) < 0 and b"no HIP device" in lib.srtLastError()
+    assert lib.srtMultiCreate(C.byref(cfg), None, 0, C.byref(h)) < 0                     # bad worker count
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
