@@ -248,7 +248,10 @@ template <int TW, int SW> struct Enc16Pad {
     static constexpr int base = TW + 4;
     static constexpr int value = SW == 32 ? base : (SW == 16 ? ((base + 3) / 8 * 8 + 4) : ((base + 5) / 8 * 8 + 2));
 };
-template <int SW, int NSX, int NSY, int NI, int NSPLIT, bool A16 = false>
+// TPW > 1 (layers with ONE 16-channel K chunk, i.e. down2): a workgroup runs TPW vertically adjacent tiles.  Such a layer is 25 MFMAs per wave and tile
+// behind a 25 KiB weight slab, a patch and an epilogue of 32 two-byte stores per lane: all per-workgroup overhead.  In the loop the slab is fetched once,
+// the next tile's patch is requested before the current tile's MFMAs and lands under them and under the epilogue.
+template <int SW, int NSX, int NSY, int NI, int NSPLIT, bool A16 = false, int TPW = 1>
 __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
 {
     static_assert(!A16 || NSPLIT == 1, "fp16 storage only with rounded activations");
@@ -272,8 +275,9 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
     const int groups = (p.ntiles + NI - 1) / NI;
-    const SrtBlockCoord bc = srt_block_coord(tilesX * tilesY, (p.Cout + BM - 1) / BM, p.nstems, groups);
-    const int tx0 = (bc.sp % tilesX) * TW, ty0 = (bc.sp / tilesX) * TH, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    const SrtBlockCoord bc = srt_block_coord(tilesX * (tilesY / TPW), (p.Cout + BM - 1) / BM, p.nstems, groups);   // (the launcher checks tilesY % TPW == 0)
+    const int tx0 = (bc.sp % tilesX) * TW, m0 = bc.mblk * BM, stem = bc.stem, tile0 = bc.grp * NI;
+    int ty0 = (bc.sp / tilesX) * TPW * TH;                                   // advances tile by tile when TPW > 1
     const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
     const size_t hw = (size_t)p.H * p.W;
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
@@ -351,10 +355,6 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
     };
 
     f32x16 acc[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     int boff[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
@@ -382,17 +382,23 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
         }
         __syncthreads();
     }
-    const int nchunks = p.Cin / 16;
+    const int nchunks = TPW > 1 ? 1 : p.Cin / 16;
     srt_dma_slab16(wp, p.CP, s_w, wave, lane);
     load_patch(0);
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_patch(ch);
+        store_patch(ch);                                                     // (its border tests use the tile the registers were loaded for: see below)
         __syncthreads();
         const _Float16* sw = s_w + (ch & 1) * WSLAB;
         if (ch + 1 < nchunks) {
             srt_dma_slab16(wp + (size_t)(ch + 1) * cgStride, p.CP, s_w + ((ch + 1) & 1) * WSLAB, wave, lane);
             load_patch(ch + 1);
         }
+        if (TPW > 1 && t + 1 < TPW) { ty0 += TH; load_patch(0); ty0 -= TH; }  // the next tile's patch: in flight under this tile's MFMAs and epilogue
 #pragma unroll
         for (int tap = 0; tap < 25; ++tap) {
             const int ky = tap / 5, kx = tap % 5;
@@ -445,6 +451,8 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
             if (pix_ok && m < p.Cout) p.outRaw[obase + (size_t)m * ohw] = acc[nr][r] + bi[r];      // conv + bias, stored once
         }
     }
+    ty0 += TH;
+    }                                                                        // tiles of the workgroup
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
@@ -482,6 +490,16 @@ int srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s)
     if (Wo >= 64) {
         if (v == 1) return launch_enc16<32, 2, 4, 1>(p, s);                  // 4 rows x 64 cols: 99 KB LDS, 1 workgroup / CU
         if (v == 2) return launch_enc16<32, 2, 2, 1>(p, s);                  // 2 rows x 64 cols
+        // one K chunk (down2), fp16 storage, a batch that still fills the chip with a quarter of the workgroups: four tiles per workgroup (see srt_enc_f16, TPW)
+        if (p.Cin == 16 && p.in16 && p.nsplit == 1 && v != 3) {
+            constexpr int TPW = 4, TH = 4, TW = 32;
+            const int Ho = p.H / 2, tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
+            const long wgs = (long)tilesX * (tilesY / TPW) * ((p.Cout + 31) / 32) * p.nstems * p.ntiles;
+            if (tilesY % TPW == 0 && wgs >= 1024) {
+                SRT_LAUNCH((srt_enc_f16<32, 1, 4, 1, 1, true, TPW>), dim3((unsigned)wgs), dim3(256), 0, s, p);
+                return srt_launch_status();
+            }
+        }
         return launch_enc16<32, 1, 4, 1>(p, s);                              // 4 rows x 32 cols: 76 KB LDS, 2 workgroups / CU
     }
     if (Wo >= 32) {

@@ -924,6 +924,8 @@ def test_down1_streamed_form(oracle, coeffs, T, F, ntiles, stems, prec):
     gact = {k: eng.tensor("conv2", *k) for k in got} if f16 else {}
     ks = _layer_kernels(eng, xd)
     assert ks["down1"].startswith("srt_down1_stream_kernel<"), ks["down1"]
+    if f16:                                                     # down2 of this mode: the four-tiles-per-workgroup form of the one-chunk fp16 layer (csrc/srt_nn3.hip, TPW)
+        assert ks["down2"].startswith("srt_enc_f16<32, 1, 4, 1, 1, true, 4"), ks["down2"]
     lo = oracle.layout()
     for (s, t), g in got.items():
         c = coeffs(s)
@@ -939,6 +941,8 @@ def test_down1_streamed_form(oracle, coeffs, T, F, ntiles, stems, prec):
         eng.forward(one)
         k1 = _layer_kernels(eng, one)
         assert k1["down1"].startswith("srt_enc_mfma2<"), k1["down1"]
+        if f16:
+            assert k1["down2"].startswith("srt_enc_f16<32, 1, 4, 1, 1, true, 1"), k1["down2"]
         for s in range(stems):
             assert np.array_equal(eng.tensor("conv1", s, 0), got[(s, t)]), (s, t)
             if f16:
