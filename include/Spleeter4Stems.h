@@ -20,9 +20,10 @@
  */
 #ifndef SPLEETERRT_AMD_SPLEETER4STEMS_H
 #define SPLEETERRT_AMD_SPLEETER4STEMS_H
-#ifdef __cplusplus
-extern "C" {
-#endif
+/* Everything a translation unit gets from the reference header besides the three functions is kept, because the
+   plugin relies on it: PluginProcessor.cpp:6-9 includes ONLY this header and then calls getCoeffSize() (:48, declared by
+   the nested spleeter.h, Spleeter4Stems.h:23) and min(n - offset, OVPSIZE) (:178, the macro of Spleeter4Stems.h:10-12).
+   tests/test_plugin_header.py compiles a caller of that shape against this header (and against the reference's). */
 #ifndef FFTSIZE
 #define FFTSIZE 4096
 #endif
@@ -30,8 +31,25 @@ extern "C" {
 #define OVPSIZE (FFTSIZE / ANALYSIS_OVERLAP)
 #define OUTPUTSEG ((OVPSIZE >> 1) << 1)
 #define SAMPLESHIFT (FFTSIZE - (OVPSIZE << 1))
+#define MINUSFFTSIZE (FFTSIZE - 1)
+#ifndef HALFWNDLEN
+#define HALFWNDLEN ((FFTSIZE >> 1) + 1)
+#endif
+#define MAX_OUTPUT_BUFFERS 2
 #define LATENCY ((OVPSIZE << 1) - OUTPUTSEG)
+#ifndef min
+#define min(a,b) (((a)<(b))?(a):(b))
+#endif
 #define COMPONENTS 8
+#define TASK_NB 5
+#ifndef SRT_PT_STATE_DEFINED   /* Spleeter4Stems.h:14-20; stftFix.h declares the same enum */
+#define SRT_PT_STATE_DEFINED
+enum pt_state { SETUP, IDLE, WORKING, GET_OFF_FROM_WORK };
+#endif
+#include "spleeter.h"           /* tile API + weight-layout types, as Spleeter4Stems.h:23 */
+#ifdef __cplusplus
+extern "C" {
+#endif
 typedef struct
 {
     void *impl;                  /* engine + device buffers + host ring/queue state */

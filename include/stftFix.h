@@ -19,7 +19,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#ifndef SRT_PT_STATE_DEFINED
+#define SRT_PT_STATE_DEFINED
 enum pt_state { SETUP, IDLE, WORKING, GET_OFF_FROM_WORK };
+#endif
 #define FFTSIZE 4096
 #define LAP 4
 #define HOPSIZE (FFTSIZE / LAP)

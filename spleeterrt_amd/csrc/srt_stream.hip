@@ -8,13 +8,14 @@
 // engine's own stream (the reference's task_type2 threads, Spleeter4Stems.c:135,351-371) and joined one batch later.
 #include "srt_internal.h"
 #include "../../include/spleeterrt_amd.h"
-#include "../../include/Spleeter4Stems.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
+#include "../../include/Spleeter4Stems.h"
+#undef min   // the header keeps the reference's C macro (Spleeter4Stems.h:10-12) for the plugin; not wanted in this C++ file
 
 // Failure policy (this is the host's real-time audio thread, VST/Source/PluginProcessor.cpp:178-179): never abort(), never a
 // CPU path.  The first failure is reported once (stderr + srtLastError()), the instance is marked failed and from then on it
