@@ -68,6 +68,7 @@ SRT_API size_t srtCoeffBytes(void);                                           /*
 SRT_API int  srtSetCoeffHost(srt_engine *e, int stem, const void *h_coeff);
 SRT_API int  srtSetCoeffDevice(srt_engine *e, int stem, const void *d_coeff);
 SRT_API int  srtSetCoeffFp16Host(srt_engine *e, int stem, const uint16_t *h_halfs);   /* spleeterQuantizedSubNet */
+SRT_API int  srtGetCoeffHost(srt_engine *e, int stem, void *h_coeff);                 /* read the stored fp32 blob back (srtCoeffBytes() bytes): tests of the fp16 expansion */
 
 /* d_mag: [ntiles][2][T][F] magnitudes; d_masks: [n_stems][ntiles][2][T][F] */
 SRT_API int  srtForward(srt_engine *e, const float *d_mag, int ntiles, float *d_masks);
@@ -151,6 +152,13 @@ SRT_API int  srtMultiSeparateHost(srt_multi *m, const float *h_L, const float *h
 SRT_API int  srtMultiSeparateCliHost(srt_multi *m, const float *h_L, const float *h_R, size_t n, int stems, float *h_out);
 /* "engines=2 devices=0,1 distinct=2 weights=rccl broadcasts=2" (tests, logs); returns the number of engines */
 SRT_API int  srtMultiInfo(const srt_multi *m, char *text, size_t bytes);
+/* engine g of the object (borrowed; for srtSetTiming / srtGetTiming* / srtCopyTensor on it), NULL outside [0, engines) */
+SRT_API srt_engine *srtMultiEngine(srt_multi *m, int g);
+/* Resident throughput of all engines at once, the measurement `bench.py --host native` reports: every worker thread fills `tiles` (<= max_tiles)
+ * tiles of synthetic PCM in its device's HBM, runs `warmup` untimed srtSeparate passes, meets the others at a barrier, runs `steps` passes and
+ * synchronises its device.  *seconds = first worker released -> last worker done.  seconds_events (may be NULL): the same K passes once more with
+ * per-launch HIP events switched on for engine 0 (read them with srtGetTiming(srtMultiEngine(m, 0), ...); timing stays on). */
+SRT_API int  srtMultiBenchResident(srt_multi *m, int tiles, int steps, int warmup, double *seconds, double *seconds_events);
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */

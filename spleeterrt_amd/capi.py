@@ -49,6 +49,7 @@ def load_library():
     L.srtSetCoeffHost.argtypes = [vp, C.c_int, vp]
     L.srtSetCoeffDevice.argtypes = [vp, C.c_int, vp]
     L.srtSetCoeffFp16Host.argtypes = [vp, C.c_int, vp]
+    L.srtGetCoeffHost.argtypes = [vp, C.c_int, vp]
     L.srtForward.argtypes = [vp, f32p, C.c_int, f32p]
     L.srtForwardStems.argtypes = [vp, f32p, C.c_int, f32p, C.c_int, C.c_int]
     L.srtRatioMask.argtypes = [vp, f32p, C.c_int]
@@ -81,6 +82,9 @@ def load_library():
     L.srtMultiSeparateHost.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint]
     L.srtMultiSeparateCliHost.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.srtMultiInfo.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.srtMultiEngine.argtypes = [vp, C.c_int]
+    L.srtMultiEngine.restype = vp
+    L.srtMultiBenchResident.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -148,6 +152,13 @@ class Engine:
         a = np.ascontiguousarray(halfs, np.uint16)
         assert a.size == COEFF_FLOATS
         self._chk(self.L.srtSetCoeffFp16Host(self.h, stem, C.c_void_p(a.ctypes.data)))
+
+    def get_coeff(self, stem):
+        """the fp32 blob the engine holds for a sub-network (after set_coeff_fp16: the expanded container)"""
+        import numpy as np
+        a = np.empty(COEFF_FLOATS, np.float32)
+        self._chk(self.L.srtGetCoeffHost(self.h, stem, C.c_void_p(a.ctypes.data)))
+        return a
 
     # ---- stages (all tensors live on self.device)
     def forward(self, mag, masks=None):

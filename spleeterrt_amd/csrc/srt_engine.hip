@@ -332,6 +332,16 @@ int srtSetCoeffDevice(srt_engine* e, int stem, const void* d)
     HIPCHK(hipMemcpyAsync(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, d, srtCoeffBytes(), hipMemcpyDeviceToDevice, e->stream));
     return pack_stem(e, stem);
 }
+// read the fp32 blob of a sub-network back (what srtSetCoeff* stored: for the fp16 container, the expanded values)
+int srtGetCoeffHost(srt_engine* e, int stem, void* h)
+{
+    if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtGetCoeffHost: bad argument");
+    SrtSetupLock setup;
+    DeviceScope ds(e->device);
+    HIPCHK(hipMemcpyAsync(h, e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE, srtCoeffBytes(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
 int srtSetCoeffFp16Host(srt_engine* e, int stem, const uint16_t* h)
 {
     if (!e || !h || stem < 0 || stem >= e->cfg.n_stems) return fail(-1, "srtSetCoeffFp16Host: bad argument");

@@ -19,6 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -312,4 +315,79 @@ int srtMultiSeparateCliHost(srt_multi* m, const float* h_L, const float* h_R, si
 {
     if (stems != 2 && stems != 3) return mfail(-1, "srtMultiSeparateCliHost: stems must be 2 or 3");
     return multi_run(m, h_L, h_R, n, h_out, 0, stems);
+}
+
+srt_engine* srtMultiEngine(srt_multi* m, int g)
+{
+    return (m && g >= 0 && g < (int)m->eng.size()) ? m->eng[g] : nullptr;
+}
+
+// ---- resident throughput on every engine at once (bench.py --host native): the C host of main.c:544-673's shape - one process, one worker
+// thread + engine per device - timed the way the per-process bench times its ranks: warm-up, a barrier over the workers, `steps` passes of
+// the whole path (srtSeparate, PCM and stems resident in each device's HBM), device synchronised, barrier; the clock runs from the first
+// worker leaving the first barrier to the last one finishing.
+namespace {
+struct WorkerBarrier {
+    std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long gen = 0;
+    explicit WorkerBarrier(int n_) : n(n_) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+}
+
+int srtMultiBenchResident(srt_multi* m, int tiles, int steps, int warmup, double* seconds, double* seconds_events)
+{
+    if (!m || !seconds || tiles < 1 || tiles > m->cfg.max_tiles || steps < 1 || warmup < 0) return mfail(-1, "srtMultiBenchResident: bad argument");
+    const int G = (int)m->eng.size(), NP = 2 * m->cfg.n_stems;
+    const size_t n = (size_t)tiles * m->cfg.T * SRT_HOP, olen = srtIstftLength(srtStftRows(n));
+    typedef std::chrono::steady_clock clk;
+    std::vector<int> rc(G, 0);
+    std::vector<std::string> err(G);
+    std::vector<clk::time_point> t0(G), t1(G), e0(G), e1(G);
+    WorkerBarrier bar(G);
+    int prev = 0; (void)hipGetDevice(&prev);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g]() {
+            hipSetDevice(m->dev[g]);
+            float *dL = nullptr, *dR = nullptr, *dO = nullptr;
+            std::vector<float> h(2 * n);
+            uint32_t st = 777u + (uint32_t)g;                       // SURVEY 8d's LCG, white noise of +-0.1
+            for (size_t i = 0; i < 2 * n; ++i) { st = st * 1664525u + 1013904223u; h[i] = 0.2f * ((float)(st >> 8) * (1.0f / 16777216.0f) - 0.5f); }
+            bool ok = hipMalloc((void**)&dL, n * 4) == hipSuccess && hipMalloc((void**)&dR, n * 4) == hipSuccess && hipMalloc((void**)&dO, (size_t)NP * olen * 4) == hipSuccess &&
+                      hipMemcpy(dL, h.data(), n * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dR, h.data() + n, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) { rc[g] = -2; err[g] = "srtMultiBenchResident: device allocation / upload failed"; }
+            auto pass = [&](int k) { for (int i = 0; i < k && !rc[g]; ++i) if ((rc[g] = srtSeparate(m->eng[g], dL, dR, n, dO)) != 0) err[g] = srtLastError(); };
+            auto drain = [&]() { if (!rc[g] && hipStreamSynchronize(m->stream[g]) != hipSuccess) { rc[g] = -2; err[g] = "srtMultiBenchResident: stream failed"; } };
+            pass(warmup); drain();
+            bar.wait(); t0[g] = clk::now();
+            pass(steps); drain();
+            t1[g] = clk::now(); bar.wait();
+            if (seconds_events) {                                   // the same K passes with HIP events around every launch of engine 0 (srtGetTiming)
+                if (g == 0 && !rc[g]) srtSetTiming(m->eng[0], 1);
+                bar.wait(); e0[g] = clk::now();
+                pass(steps); drain();
+                e1[g] = clk::now(); bar.wait();
+            }
+            if (dL) hipFree(dL);
+            if (dR) hipFree(dR);
+            if (dO) hipFree(dO);
+        });
+    }
+    for (auto& t : th) t.join();
+    hipSetDevice(prev);
+    for (int g = 0; g < G; ++g) if (rc[g]) return mfail(rc[g], "%s", err[g].c_str());
+    auto span = [&](std::vector<clk::time_point>& a, std::vector<clk::time_point>& b) {
+        clk::time_point lo = a[0], hi = b[0];
+        for (int g = 1; g < G; ++g) { if (a[g] < lo) lo = a[g]; if (b[g] > hi) hi = b[g]; }
+        return std::chrono::duration<double>(hi - lo).count();
+    };
+    *seconds = span(t0, t1);
+    if (seconds_events) *seconds_events = span(e0, e1);
+    return 0;
 }

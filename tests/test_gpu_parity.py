@@ -277,6 +277,38 @@ def test_fp16_container(oracle):
     e1.close(); e2.close()
 
 
+def half_patterns_expected():
+    """f32Decompress (Executable/main.c:423-434) worked out by hand for every one of the 65 536 half patterns, without the oracle's C:
+    exponent 0 -> signed zero (denormals flushed); exponent 1..30 -> the IEEE value (numpy's own half -> float conversion); exponent 31 is NOT
+    special-cased by the reference: the bits are re-biased like a normal number, giving +-65536 * (1 + m/1024) instead of Inf / NaN."""
+    h = np.arange(65536, dtype=np.uint32)
+    sign, ex, man = h >> 15, (h >> 10) & 31, h & 1023
+    with np.errstate(all="ignore"):
+        val = h.astype(np.uint16).view(np.float16).astype(np.float32)
+    val = np.where(ex == 0, np.where(sign == 1, np.float32(-0.0), np.float32(0.0)), val)
+    top = (65536.0 * (1.0 + man / 1024.0)).astype(np.float32)
+    val = np.where(ex == 31, np.where(sign == 1, -top, top), val).astype(np.float32)
+    return val
+
+
+def test_fp16_expand_all_65536_patterns(oracle):
+    """VERDICT r4 missing #3: the GPU expand kernel, the oracle's C restatement and the hand-derived table agree BIT FOR BIT on every half
+    pattern (Inf/NaN patterns included - the reference does not special-case them).  main.c:423-434 itself cannot be built here (model.c absent)."""
+    import spleeterrt_amd as srt
+    want = half_patterns_expected()
+    allh = np.arange(65536, dtype=np.uint16)
+    assert np.array_equal(oracle.fp16_expand(allh).view(np.uint32), want.view(np.uint32))
+    n = 9822725
+    rng = np.random.RandomState(7)
+    h = np.concatenate([allh, rng.permutation(allh), rng.randint(0, 65536, n - 2 * 65536).astype(np.uint16)])       # every pattern at least twice, at aligned and odd positions
+    eng = _engine(F=512, T=64, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1)
+    eng.set_coeff_fp16(0, h)
+    got = eng.get_coeff(0)
+    eng.close()
+    assert np.array_equal(got.view(np.uint32), want[h].view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), oracle.fp16_expand(h).view(np.uint32))
+
+
 def test_stft_matches_oracle(oracle):
     import torch
     n = 4096 * 6 + 8192 + 1500                               # ragged tail: last frame is zero padded

@@ -63,6 +63,34 @@ def test_cli_program_with_several_gpu_workers(tmp_path, oracle, stems):
         assert np.array_equal(outs["two"][nm], outs["peer"][nm])
 
 
+def test_native_host_bench_line_equals_the_per_process_line():
+    """bench.py --gpus 1 --host native (one process, the C host srtMultiCreate + worker thread + srtMultiBenchResident) times the same work as the
+    plain line: same kernels, step time within 3 % (best of three pairs: two separate processes on a shared box)."""
+    import json
+    import sys
+
+    def run(extra):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "3", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    best = None
+    for _ in range(3):
+        plain, native = run([]), run(["--host", "native"])
+        assert native["n_gpus"] == 1 and native["host"].startswith("native") and native["distributed"]["backend"].startswith("rccl"), native["host"]
+        assert native["layer_kernels"] == plain["layer_kernels"] and native["config"] == plain["config"]
+        assert 0.0 < native["roofline"]["frac"] <= 1.0
+        rel = abs(native["ms_per_step"] - plain["ms_per_step"]) / plain["ms_per_step"]
+        best = rel if best is None else min(best, rel)
+        if best <= 0.03:
+            break
+    print("plain %.3f ms/step, native host %.3f ms/step" % (plain["ms_per_step"], native["ms_per_step"]))
+    assert best <= 0.03, best
+
+
 def test_multi_engine_stream_equals_single_engine(oracle, coeffs):
     """srtMultiSeparateHost (4 sub-networks on the same input, three engines on device 0, ragged last range) == one engine's
     srtSeparateHostStream, and the library maps librccl only once a multi-device object exists."""
@@ -100,6 +128,17 @@ def test_multi_engine_stream_equals_single_engine(oracle, coeffs):
     assert out.shape == ref.shape and np.isfinite(out).all()
     assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max(), float(np.abs(out - ref).max() / np.abs(ref).max())
     assert np.array_equal(out, again)                           # reusable, deterministic
+    # and DIRECTLY against the oracle chain (stft -> processMT -> istft, main.c:776-785) - not only multi == single: two sub-networks, whole
+    # stream, so every range (2 / 2 / 1 tiles) and both seams are inside the comparison
+    re, im = oracle.stft(Lh, Rh)
+    for s, mode in ((0, 1), (1, 0)):
+        r, i = re.copy(), im.copy()
+        oracle.process_spectrogram(coeffs(s), r, i, F, T, mode, oracle.VARIANT_VST, 0.1)
+        want = oracle.istft(r, i)
+        err = np.sqrt(np.mean((out[s] - want) ** 2)) / np.sqrt(np.mean(want ** 2))
+        assert err <= 1e-4 and np.abs(out[s] - want).max() <= 1e-4 * np.abs(want).max(), (s, float(err))
+        for g0 in (2 * T * 1024, 4 * T * 1024):                 # the seam samples themselves (range boundaries at tiles 2 and 4) carry signal
+            assert np.abs(want[:, g0:g0 + 3072]).max() > 1e-3 * np.abs(want).max()
     # bad device index: refused, nothing created
     bad = (C.c_int * 2)(0, 99)
     assert lib.srtMultiCreate(C.byref(cfg), bad, 2, C.byref(h)) < 0 and b"device index" in lib.srtLastError()

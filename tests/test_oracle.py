@@ -210,3 +210,19 @@ def test_cli_flow_restatement_vs_reference_linked_harness(oracle, tmp_path, stem
         a = got[k][:, 4096:4096 + n].T
         assert a.shape == r.shape
         assert np.abs(a - r).max() <= 2e-6 * max(np.abs(r).max(), 1e-3), "%s: %g" % (nm, np.abs(a - r).max())
+
+
+def test_oracle_fp16_expand_every_pattern(oracle):
+    """The oracle's restatement of f32Decompress (Executable/main.c:423-434) against a table worked out by hand for all 65 536 half patterns:
+    exponent 0 -> signed zero, exponent 1..30 -> the IEEE value, exponent 31 re-biased like a normal (+-65536 * (1 + m/1024); no Inf/NaN)."""
+    h = np.arange(65536, dtype=np.uint32)
+    sign, ex, man = h >> 15, (h >> 10) & 31, h & 1023
+    bits = np.where(ex == 0, sign << 31, (sign << 31) | ((ex + 112) << 23) | (man << 13)).astype(np.uint32)     # 112 = 127 - 15: main.c:430 adds 0x38000000
+    got = oracle.fp16_expand(h.astype(np.uint16))
+    assert np.array_equal(got.view(np.uint32), bits)
+    with np.errstate(all="ignore"):
+        ieee = h.astype(np.uint16).view(np.float16).astype(np.float32)
+    normal = (ex >= 1) & (ex <= 30)
+    assert np.array_equal(got[normal], ieee[normal])                                     # and numpy's own conversion agrees wherever IEEE defines a finite normal
+    assert np.all(got[ex == 0] == 0) and np.all(np.signbit(got[(ex == 0) & (sign == 1)]))
+    assert np.all(np.isfinite(got)) and np.abs(got[ex == 31]).min() == 65536.0

@@ -40,16 +40,22 @@ def _launch(args, distributed):
 
 def test_bench_line_under_a_world_of_one_nccl_group():
     args = ["bench.py", "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]
-    plain = _launch(args, False)
-    dist = _launch(args, True)
-    assert plain["distributed"] is None
-    assert dist["distributed"]["backend"].startswith("nccl") and dist["distributed"]["world"] == 1 and dist["n_gpus"] == 1
-    for d in (plain, dist):
-        assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["kernel"].startswith("srt_")
-    assert plain["layer_kernels"] == dist["layer_kernels"]
-    # same work, same kernels: joining the group must not change the step time beyond run-to-run noise (two separate processes, a shared box: a
-    # generous bound - what this catches is a collective or a sync that crept into the timed loop, which costs far more than 15 %)
-    assert abs(dist["ms_per_step"] - plain["ms_per_step"]) <= 0.15 * plain["ms_per_step"], (plain["ms_per_step"], dist["ms_per_step"])
+    best = None
+    for _ in range(3):
+        plain = _launch(args, False)
+        dist = _launch(args, True)
+        assert plain["distributed"] is None
+        assert dist["distributed"]["backend"].startswith("nccl") and dist["distributed"]["world"] == 1 and dist["n_gpus"] == 1
+        for d in (plain, dist):
+            assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["kernel"].startswith("srt_")
+        assert plain["layer_kernels"] == dist["layer_kernels"]
+        rel = abs(dist["ms_per_step"] - plain["ms_per_step"]) / plain["ms_per_step"]
+        best = rel if best is None else min(best, rel)
+        if best <= 0.06:
+            break
+    # same work, same kernels: joining the group must not change the step time beyond run-to-run noise (6 %, best of up to three pairs of separate
+    # processes on a shared box; a collective or a sync that crept into the timed loop costs far more, every time)
+    assert best <= 0.06, (plain["ms_per_step"], dist["ms_per_step"])
     print("N=1 plain %.3f ms/step, N=1 under nccl world=1 %.3f ms/step" % (plain["ms_per_step"], dist["ms_per_step"]))
 
 
