@@ -220,15 +220,20 @@ class Engine:
         self._chk(self.L.srtSeparateCli(self.h, _ptr(L.contiguous()), _ptr(R.contiguous()), n, stems, _ptr(out)))
         return out
 
-    def separate_cli_host(self, L, R, stems):
+    def separate_cli_host(self, L, R, stems, keep_staging=False):
         """the CLI flow from host buffers (numpy float32), any length: one resident batch when the file fits max_tiles tiles, otherwise
-        chunk by chunk (srtSeparateCliHost) -> numpy [stems,2,len]"""
+        chunk by chunk (srtSeparateCliHost) -> numpy [stems,2,len].  The call's device staging (whole-file PCM + outputs for a file that fits, O(file)
+        bytes of HBM) is released afterwards unless keep_staging=True (a caller that separates file after file keeps it to avoid re-allocating)."""
         import numpy as np
         L = np.ascontiguousarray(L, np.float32)
         R = np.ascontiguousarray(R, np.float32)
         assert L.size == R.size
         out = np.empty((stems, 2, self.L.srtIstftLength(self.L.srtStftRows(L.size))), np.float32)
-        self._chk(self.L.srtSeparateCliHost(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), L.size, stems, C.c_void_p(out.ctypes.data)))
+        try:
+            self._chk(self.L.srtSeparateCliHost(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), L.size, stems, C.c_void_p(out.ctypes.data)))
+        finally:
+            if not keep_staging:
+                self.L.srtReleaseStaging(self.h)
         return out
 
     def separate_host_stream(self, L, R, frames=None, rows=None, out=None, pinned=False):

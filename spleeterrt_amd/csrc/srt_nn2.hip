@@ -449,6 +449,12 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
 // 4 (l31 % 16) + nr: four consecutive pixels of every channel row per lane = one float4 store.
 // Input ring in LDS: 32 rows x 2 channels x 144 floats (input columns 2 ox0 - 4 .. 2 ox0 + 139), row r of the image at ring row r & 31; chunk c = rows
 // 8 c .. 8 c + 7 = 9 DMA pieces.  Interval i reads rows 8 i - 1 .. 8 i + 9: chunks i - 1 (its last row), i, i + 1 while chunk i + 2 lands.
+// The counted wait below relies on gfx9-family vmcnt semantics (loads, LDS-DMA and stores retire through ONE in-order counter) and on the compiler
+// emitting exactly one VM instruction per 16-byte (float4) / 8-byte (h4) store with nothing spilled to scratch.  The first is pinned here, the second by
+// tests/test_abi.py::test_down1_stream_store_count_matches_its_vmcnt_wait, which counts the stores in the ISA of both instantiations.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "srt_down1_stream_kernel's s_waitcnt vmcnt(n) bookkeeping is written for gfx942 / gfx950"
+#endif
 #define SRT_D1S_PITCH 144
 typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
 // H16 (fp16 activation storage, srt_config.precision F16): conv + bias AND act(BN(.)) leave as halves, two 8-byte stores per channel row (see srt_enc_mfma2, twoOut)

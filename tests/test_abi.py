@@ -3,6 +3,7 @@ pure-host geometry calls, and refuses (loudly, with an error code) to create an 
 import ctypes as C
 import os
 import re
+import shutil
 import subprocess
 
 import pytest
@@ -167,3 +168,35 @@ def test_bench_roofline_peaks_follow_the_precision():
     assert bench.layer_bytes("up2", "f16", True) == (512 * 8 * 32 + 128 * 16 * 64) * 2
     assert bench.layer_bytes("down2", "f16", True) == 16 * 128 * 512 * 2 + 32 * 64 * 256 * 2 * 2          # raw + act copy, halves
     assert bench.layer_bytes("up6", "f16", True) == 32 * 128 * 512 * 2 + 256 * 1024 * 4                    # up6's output stays fp32
+
+
+def test_down1_stream_store_count_matches_its_vmcnt_wait(tmp_path):
+    """srt_down1_stream_kernel proves "my LDS-DMA pieces have landed" with s_waitcnt vmcnt(nst), nst = the stores a wave issues per interval
+    (8 per live 16-row stem group, x2 with fp16 storage).  That holds only if the compiler emits exactly ONE VM instruction per float4 / h4 store and spills
+    nothing to scratch.  Checked on the ISA of both shipped instantiations: store count, scratch size, and the vmcnt immediates of the kernel."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "spleeterrt_amd", "csrc")
+    asm = tmp_path / "nn2.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "srt_nn2.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = asm.read_text().split("\n")
+    for mangled, stores_per_group in (("_Z23srt_down1_stream_kernelILi0ELb0EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1EEv13SrtConvParams", 16)):
+        start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
+        end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
+        body = [l.strip() for l in txt[start:end] if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
+        meta = [l for l in txt[start:end] if ".amdhsa_private_segment_fixed_size" in l]
+        assert meta and meta[0].split()[-1] == "0", meta                                   # nothing spilled: no hidden scratch stores in vmcnt
+        assert not [l for l in body if l.startswith("scratch_")]
+        stores = [l for l in body if l.startswith("global_store") or l.startswith("buffer_store")]
+        # every store of the kernel sits in the interval loop: two 16-row stem groups (registers 0..7 / 8..15), each behind its own wave-uniform guard
+        assert len(stores) == 2 * stores_per_group, (mangled, len(stores))
+        want_op = "global_store_dwordx4" if stores_per_group == 8 else "global_store_dwordx2"
+        assert all(l.split()[0] == want_op for l in stores), sorted(set(l.split()[0] for l in stores))
+        waits = sorted(set(int(m) for l in body if l.startswith("s_waitcnt") for m in re.findall(r"vmcnt\((\d+)\)", l)))
+        # the counted waits the source asks for at the top of an interval: both groups live / one group live (the compiler's own waits are vmcnt(0) or small)
+        assert 2 * stores_per_group in waits and stores_per_group in waits, (mangled, waits)
+        dma = [l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]
+        assert len(dma) >= 3                                                               # the LDS-DMA pieces the wait is about

@@ -142,3 +142,43 @@ def test_multi_engine_stream_equals_single_engine(oracle, coeffs):
     # bad device index: refused, nothing created
     bad = (C.c_int * 2)(0, 99)
     assert lib.srtMultiCreate(C.byref(cfg), bad, 2, C.byref(h)) < 0 and b"device index" in lib.srtLastError()
+
+
+def test_two_distinct_devices_equal_single_engine(oracle, coeffs):
+    """the genuinely multi-device paths (ncclCommInitAll over > 1 device, the grouped ncclBroadcast, per-device constant tables, portable
+    host registration shared by worker threads on different devices).  Needs two GPUs: skipped on the one-GPU test box, runs wherever a node has them."""
+    import spleeterrt_amd as srt
+    from spleeterrt_amd.capi import _Config
+    lib = srt.load_library()
+    if lib.srtDeviceCount() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % lib.srtDeviceCount())
+    T, F, S = 64, 512, 2
+    n = 4096 * 70 + 8192 + 700
+    Lh, Rh = oracle.synth_audio(n, 99, True)
+    eng = srt.Engine(F=F, T=T, stem_modes=(1, 0), variant=srt.VARIANT_VST, max_tiles=2, batch_invariant=True)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    ref = eng.separate_host_stream(Lh, Rh)
+    eng.close()
+    cfg = _Config()
+    cfg.F, cfg.T, cfg.n_stems, cfg.variant, cfg.max_tiles, cfg.batch_invariant = F, T, S, srt.VARIANT_VST, 2, 1
+    for i, m in enumerate((1, 0)):
+        cfg.stem_mode[i] = m
+        cfg.oob_weight[i] = 0.1
+    for no_rccl in ("0", "1"):
+        os.environ["SPLEETERRT_NO_RCCL"] = no_rccl
+        try:
+            h = C.c_void_p()
+            assert lib.srtMultiCreate(C.byref(cfg), (C.c_int * 2)(0, 1), 2, C.byref(h)) == 0, lib.srtLastError()
+            for s in range(S):
+                c = np.ascontiguousarray(coeffs(s), np.float32)
+                assert lib.srtMultiSetCoeffHost(h, s, c.ctypes.data_as(C.c_void_p)) == 0, lib.srtLastError()
+            out = np.full((S, 2, lib.srtIstftLength(lib.srtStftRows(n))), np.nan, np.float32)
+            assert lib.srtMultiSeparateHost(h, Lh.ctypes.data_as(C.c_void_p), Rh.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), 0) == 0, lib.srtLastError()
+            info = C.create_string_buffer(256)
+            lib.srtMultiInfo(h, info, 256)
+            assert b"distinct=2" in info.value and (b"weights=rccl" if no_rccl == "0" else b"weights=peer-copy") in info.value, info.value
+            lib.srtMultiDestroy(h)
+        finally:
+            os.environ.pop("SPLEETERRT_NO_RCCL", None)
+        assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max()
