@@ -178,118 +178,6 @@ __device__ __forceinline__ void fft4096_pp(cf (&v)[16], cf* e1, cf* e2, const cf
 
 #define STFT_FPB 8      // frames per workgroup on long signals (amortises the twiddle-table load; consecutive frames share 75% of input)
 
-__global__ void __launch_bounds__(256, 2) srt_stft_kernel(const SrtStftParams p, int fpb)
-{
-    __shared__ cf s_mem[2 * FFT_SMEM_F2 + FFT_TWB_F2];   // two exchange buffers + the pass-2 twiddles (one LDS object)
-    cf* bufA = s_mem;
-    cf* bufB = s_mem + FFT_SMEM_F2;
-    cf* s_twb = s_mem + 2 * FFT_SMEM_F2;
-    const int tid = threadIdx.x;
-    const int blk = blockIdx.x;                          // (XCD order measured no better here: the input is 8 KB per frame)
-    cf twa[15];
-    fft_load_twiddles_pp(twa, s_twb, p.tab.twiddle, tid);
-    __syncthreads();
-
-    // the windowed samples of the NEXT frame are loaded while the current frame is transformed (clamped frame index:
-    // a redundant reload at the end of the run instead of a conditional assignment of the 16 staged values)
-    float nxtL[16], nxtR[16];                            // raw samples: fetch only ISSUES loads, the window multiply happens where they are consumed
-    float aw[16];                                        // this thread's 16 analysis-window taps are the same for every frame
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) aw[n2] = p.tab.preWin[tid + 256 * n2];
-    auto fetch = [&](int f) {
-        const size_t pos = (size_t)f * SRT_HOP;
-#pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            const int n = tid + 256 * n2;
-            const size_t q = pos + n < p.nsamples ? pos + n : 0;
-            nxtL[n2] = p.L[q]; nxtR[n2] = p.R[q];
-        }
-    };
-    const int flast = max(p.frames_computed, 1) - 1;
-    cf* e1 = bufA;
-    cf* e2 = bufB;
-    // Output rows of frame f (spectra of both channels + the magnitude tile row): written in iteration f + 1, after that iteration has taken
-    // its prefetched samples and before it requests the samples of frame f + 2.  vmcnt counts loads and stores in one queue: a wait for
-    // loads also waits for every store issued BEFORE them, and the compiler's count for stores issued after them is conservative across the
-    // lane-conditional blocks below - so stores right ahead of a load wait cost their acknowledgement time once per frame.  Issued ahead of
-    // the next prefetch they have a whole transform to complete.
-    auto emit = [&](int f, const cf* nat) {
-        const int tile = f / p.T, t = f % p.T;
-        float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
-        float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
-        cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
-        cf* specR = specL + p.spec_ch_stride;
-        // separate the two real spectra; stored spectrum = conj(F) (the reference's re/im convention, SURVEY §8a a12)
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int k = tid + 256 * j;
-            if (k <= 2048) {
-                const cf zk = nat[k], zm = nat[(4096 - k) & 4095];
-                const cf sl = split_l(zk, zm), sr = split_r(zk, zm);
-                specL[k] = sl;
-                specR[k] = sr;
-                if (p.mag && k < p.F) {
-                    magL[k] = hypotf(sl.x, sl.y) * 4096.0f;          // main.c:468-469
-                    magR[k] = hypotf(sr.x, sr.y) * 4096.0f;
-                }
-            } else if (k < SRT_SPEC_LD) {
-                specL[k] = f2(0.f, 0.f);
-                specR[k] = f2(0.f, 0.f);
-            }
-        }
-    };
-    int pend = -1;                                       // frame whose natural-order result waits in `nat` (LDS)
-    const cf* nat = nullptr;
-    fetch(min((int)(blk * fpb), flast));
-    for (int fi = 0; fi < fpb; ++fi) {
-        const int f = blk * fpb + fi;
-        if (f >= p.rows_total) break;
-        if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
-            if (pend >= 0) { emit(pend, nat); pend = -1; }
-            const int tile = f / p.T, t = f % p.T;
-            float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
-            float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
-            cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
-            cf* specR = specL + p.spec_ch_stride;
-            for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
-            if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
-            continue;
-        }
-        cf v[16];
-#pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            const bool ok = (size_t)f * SRT_HOP + tid + 256 * n2 < p.nsamples;   // tail frame is zero padded (stftFix.c:460-472)
-            v[n2] = f2(nxtL[n2], nxtR[n2]) * (ok ? aw[n2] : 0.f);
-        }
-        // every load of this frame's samples has returned before the first store below is issued (and the compiler's wait bookkeeping knows
-        // it: without the explicit wait it moves the multiplies above, with their waits, behind the stores)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (pend >= 0) emit(pend, nat);                  // (its LDS reads precede this frame's first transform barrier; the buffer is rewritten behind it)
-        fetch(min(f + 1, flast));
-        // exchange 1 in e1, exchange 2 in e2, natural-order result back in e1 (free once exchange 1 has been read).  The two
-        // buffers swap roles every frame: the next frame's exchange 1 goes where this frame's exchange 2 was (all of its reads
-        // precede the barrier below), and its exchange 2 - written behind the transform's first barrier - goes where this
-        // frame's output rows are read from.
-        fft4096_pp(v, e1, e2, twa, s_twb, tid);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) e1[tid + 256 * k2] = v[FFT16_AT(k2)];
-        __syncthreads();
-        nat = e1; pend = f;
-        { cf* t = e1; e1 = e2; e2 = t; }
-    }
-    if (pend >= 0) emit(pend, nat);
-}
-
-int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
-{
-    // short signals (one tile, the real-time regime): fewer frames per workgroup so that the frames spread over the CUs
-    const int fpb = p.rows_total >= 4096 ? STFT_FPB : (p.rows_total >= 1024 ? 2 : 1);
-    const int blocks = (p.rows_total + fpb - 1) / fpb;
-    if (blocks <= 0) return 0;
-    SRT_LAUNCH(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
-    return srt_launch_status();
-}
-
 // Inverse STFT with the overlap-add fused in (no frame scratch, no second pass, no atomics).
 // With the radix-16 FFT's output distribution thread w holds samples w + 256*k2 of a frame, i.e. for each of the four
 // 1024-sample quarters the SAME four in-hop offsets q_j = w + 256 j.  Overlap-add across frames is therefore
@@ -403,18 +291,264 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
     if (s1 > f0) emit_and_slide(s1 - 1);                // the last segment of the run
 }
 
+
+// ------------------------------------------------------------------------------------------- three workgroups per CU
+// Through round 4 both transforms held 2 workgroups per CU (250 / 190 VGPRs, 71.5 KB of LDS each - srt_istft_ola_kernel above is that form, kept for
+// F > 1024): with one transform per workgroup in flight the VALU, the LDS pipe and HBM take turns instead of overlapping (r04 counters: active 0.36,
+// wait 0.21 of the wave cycles, 0.33 / 0.53 of the HBM roofline).  The forms below fit THREE workgroups per CU (<= 168 VGPRs, <= 53 KB LDS; measured on
+// the 64-tile batch: iSTFT 0.587 -> 0.480 ms, STFT 0.212 -> 0.204 ms):
+//   * pass-1 twiddles from one register pair (fft_twiddle_powers) and, in the inverse, the synthesis window rebuilt from two registers per frame;
+//   * ONE exchange buffer (4 barriers per frame instead of 3: exchange 2 waits until every thread has read exchange 1);
+//   * no natural-order staging / result buffer.  What both kernels really need from LDS besides the two FFT exchanges is the HERMITIAN MIRROR:
+//     thread t owns indices t + 256 j; for j < 8 these are bins k < 2048, and the partner index 4096 - k = (256 - t) + 256 (15 - j) belongs to thread
+//     256 - t, slot 15 - j.  So only the upper half travels through LDS, 2049 values in `mir`: slot (j', t') at j' * 256 + t', read back at
+//     (15 - n2) * 256 + 256 - t (thread 0 is its own partner; its "thread 256" column is the extra entry 2048, see each kernel) - 16 KB written and
+//     read per frame instead of 32 + 32 KB, reversed-contiguous (conflict-free) on both sides.
+// LDS: 4352 + 2049 + 240 complex = 53 128 bytes.
+#define FFT_MIR_F2 2049
+// pass-1 twiddles W^(tid*k0), k0 = 1..15, from ONE register pair w1 = W^tid: powers by binary splitting (every factor is at most three products
+// deep, so the twiddles carry <= ~4 roundings = 2.4e-7 relative - inside the transform's own rounding) instead of 15 resident pairs (30 VGPRs).
+__device__ __forceinline__ void fft_twiddle_powers(cf (&v)[16], cf w1)
+{
+    const cf w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+    const cf w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+    const cf lowp[8] = { f2(1.f, 0.f), w1, w2, w3, w4, w5, w6, w7 };
+#pragma unroll
+    for (int k0 = 1; k0 < 8; ++k0) v[FFT16_AT(k0)] = cmul(v[FFT16_AT(k0)], lowp[k0]);
+    v[FFT16_AT(8)] = cmul(v[FFT16_AT(8)], w8);
+#pragma unroll
+    for (int k0 = 9; k0 < 16; ++k0) v[FFT16_AT(k0)] = cmul(cmul(v[FFT16_AT(k0)], w8), lowp[k0 - 8]);
+}
+__device__ __forceinline__ void fft4096_1b(cf (&v)[16], cf* x, const cf w1, const cf* twb, int tid)
+{
+    // in : v[n2] = x[tid + 256*n2]; `x` free (every thread is past its last read of the previous frame's exchange 2: the caller's barrier)
+    // out: v[FFT16_AT(k2)] = X[tid + 256*k2]; `x` holds exchange 2 until the caller's next barrier
+    fft16(v);
+    fft_twiddle_powers(v, w1);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; ++k0) x[k0 * FFT_EX1_LD + tid] = v[FFT16_AT(k0)];
+    __syncthreads();
+    const int lo = tid & 15, hi = tid >> 4;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = x[hi * FFT_EX1_LD + n1 * 16 + lo];
+    fft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[FFT16_AT(k1)] = cmul(v[FFT16_AT(k1)], twb[(k1 - 1) * 16 + lo]);
+    __syncthreads();                                     // every thread has read exchange 1
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) x[lo * FFT_EX2_LD + k1 * 16 + hi] = v[FFT16_AT(k1)];
+    __syncthreads();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = x[n0 * FFT_EX2_LD + tid];
+    fft16(v);
+}
+
+__global__ void __launch_bounds__(256, 3) srt_stft_kernel(const SrtStftParams p, int fpb)
+{
+    __shared__ cf s_mem[FFT_SMEM_F2 + FFT_MIR_F2 + FFT_TWB_F2];
+    cf* sx = s_mem;
+    cf* mir = s_mem + FFT_SMEM_F2;
+    cf* s_twb = mir + FFT_MIR_F2;
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const cf w1 = reinterpret_cast<const cf*>(p.tab.twiddle)[tid];
+    if (tid < FFT_TWB_F2) s_twb[tid] = reinterpret_cast<const cf*>(p.tab.twiddle)[(16 * (tid & 15) * (tid / 16 + 1)) & 4095];
+    float nxtL[16], nxtR[16];
+    float aw[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) aw[n2] = p.tab.preWin[tid + 256 * n2];
+    auto fetch = [&](int f) {
+        const size_t pos = (size_t)f * SRT_HOP;
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int n = tid + 256 * n2;
+            const size_t q = pos + n < p.nsamples ? pos + n : 0;
+            nxtL[n2] = p.L[q]; nxtR[n2] = p.R[q];
+        }
+    };
+    const int flast = max(p.frames_computed, 1) - 1;
+    fetch(min((int)(blk * fpb), flast));
+    __syncthreads();                                     // the pass-2 twiddles are in LDS
+    for (int fi = 0; fi < fpb; ++fi) {
+        const int f = blk * fpb + fi;
+        if (f >= p.rows_total) break;
+        const int tile = f / p.T, t = f % p.T;
+        float* magL = p.mag ? p.mag + ((size_t)(tile * 2 + 0) * p.T + t) * p.F : nullptr;
+        float* magR = p.mag ? p.mag + ((size_t)(tile * 2 + 1) * p.T + t) * p.F : nullptr;
+        cf* specL = reinterpret_cast<cf*>(p.spec) + (size_t)f * SRT_SPEC_LD;
+        cf* specR = specL + p.spec_ch_stride;
+        if (f >= p.frames_computed) {                    // rows the reference leaves calloc'ed (stftFix.c:368-371)
+            for (int k = tid; k < SRT_SPEC_LD; k += 256) { specL[k] = f2(0.f, 0.f); specR[k] = f2(0.f, 0.f); }
+            if (p.mag) for (int k = tid; k < p.F; k += 256) { magL[k] = 0.f; magR[k] = 0.f; }
+            continue;
+        }
+        cf v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const bool ok = (size_t)f * SRT_HOP + tid + 256 * n2 < p.nsamples;   // tail frame is zero padded (stftFix.c:460-472)
+            v[n2] = f2(nxtL[n2], nxtR[n2]) * (ok ? aw[n2] : 0.f);
+        }
+        fetch(min(f + 1, flast));                        // next frame's samples fly under this transform
+        fft4096_1b(v, sx, w1, s_twb, tid);               // v[FFT16_AT(k2)] = Z[tid + 256 k2]
+        // upper half into the mirror buffer: slot (k2 - 8, tid); entry 2048 = Z[0] (partner of bin 0, read by thread 0 through its "column 256")
+#pragma unroll
+        for (int k2 = 8; k2 < 16; ++k2) mir[(k2 - 8) * 256 + tid] = v[FFT16_AT(k2)];
+        if (tid == 0) mir[2048] = v[FFT16_AT(0)];
+        const cf z2048 = v[FFT16_AT(8)];                 // thread 0: Z[2048], its own partner
+        __syncthreads();                                 // also: every thread is done with exchange 2 (sx is free for the next frame)
+        // separate the two real spectra; stored spectrum = conj(F) (the reference's re/im convention, SURVEY 8a a12)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = tid + 256 * j;
+            const cf zk = v[FFT16_AT(j)], zm = mir[(7 - j) * 256 + 256 - tid];
+            const cf sl = split_l(zk, zm), sr = split_r(zk, zm);
+            if (p.mag && k < p.F) {
+                magL[k] = hypotf(sl.x, sl.y) * 4096.0f;              // main.c:468-469
+                magR[k] = hypotf(sr.x, sr.y) * 4096.0f;
+            }
+            specL[k] = sl;
+            specR[k] = sr;
+        }
+        if (tid < SRT_SPEC_LD - 2048) {                  // bin 2048 and the zero padding of the row
+            const cf sl = tid == 0 ? split_l(z2048, z2048) : f2(0.f, 0.f), sr = tid == 0 ? split_r(z2048, z2048) : f2(0.f, 0.f);
+            specL[2048 + tid] = sl;
+            specR[2048 + tid] = sr;
+            if (p.mag && tid == 0 && 2048 < p.F) { magL[2048] = hypotf(sl.x, sl.y) * 4096.0f; magR[2048] = hypotf(sr.x, sr.y) * 4096.0f; }
+        }
+    }
+}
+
+// NM: mask rows cover bins < F <= 256 NM, so only the first NM of a thread's eight bins can carry a mask value (F = 1024: 4 prefetch registers per channel instead of 8)
+template <int NM>
+__global__ void __launch_bounds__(256, 3) srt_istft_ola3_kernel(const SrtIstftParams p, int G)
+{
+    const int pos = srt_xcd_order(gridDim.x), stem = pos % p.nstems, run = pos / p.nstems;       // stem fastest: the stems of a run share the spectrum rows in L2
+    __shared__ cf s_mem[FFT_SMEM_F2 + FFT_MIR_F2 + FFT_TWB_F2];
+    cf* sx = s_mem;
+    cf* mir = s_mem + FFT_SMEM_F2;
+    cf* s_twb = mir + FFT_MIR_F2;
+    const int tid = threadIdx.x;
+    const cf w1 = reinterpret_cast<const cf*>(p.tab.twiddle)[tid];
+    if (tid < FFT_TWB_F2) s_twb[tid] = reinterpret_cast<const cf*>(p.tab.twiddle)[(16 * (tid & 15) * (tid / 16 + 1)) & 4095];
+    const size_t tf = (size_t)p.T * p.F;
+    const int nseg = p.frames + 3;
+    const int s0 = run * G, s1 = min(s0 + G, nseg);
+    const float oob = p.oob[stem];                                           // bins >= F: "unaffectedWeight" (main.c:486-493)
+    const cf* spec = reinterpret_cast<const cf*>(p.spec);
+    float* oL = p.out + (size_t)(stem * 2 + 0) * p.out_len;
+    float* oR = p.out + (size_t)(stem * 2 + 1) * p.out_len;
+    cf acc[4][4];                                       // [segment slot][j] = (R, L) pairs
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = f2(0.0f, 0.0f);
+    cf sl[8], sr[8];
+    float gl[NM], gr[NM];
+    cf sl8, sr8;                                        // bin 2048 (only thread 0 uses it; the address is uniform)
+    const bool has_mask = p.masks != nullptr;
+    auto fetch = [&](int f) {                                               // 0 <= f < p.frames
+        const int tile = f / p.T, t = f % p.T;
+        const cf* specL = spec + (size_t)f * SRT_SPEC_LD;
+        const cf* specR = specL + p.spec_ch_stride;
+        const float* mL = has_mask ? p.masks + ((size_t)(stem * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : p.tab.postWin;
+        const float* mR = has_mask ? mL + tf : p.tab.postWin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = tid + 256 * j;
+            sl[j] = specL[k]; sr[j] = specR[k];
+            if (j < NM) { const int km = min(k, p.F - 1); gl[j] = mL[km]; gr[j] = mR[km]; }
+        }
+        sl8 = specL[2048]; sr8 = specR[2048];
+    };
+    // the 16 synthesis-window taps of this thread (samples tid + 256 k2) are rebuilt per frame from two registers: cos / sin of th = 2 pi (tid + 1/2) / 4096, over 3
+    float ws3, wc3;
+    sincospif((tid + 0.5f) * (1.0f / 2048.0f), &ws3, &wc3);
+    ws3 *= 1.0f / 3.0f; wc3 *= 1.0f / 3.0f;
+    constexpr float COS_PI8[16] = { 1.0f, 0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f, -0.38268343236508977173f, -0.70710678118654752440f, -0.92387953251128675613f,
+                                    -1.0f, -0.92387953251128675613f, -0.70710678118654752440f, -0.38268343236508977173f, 0.0f, 0.38268343236508977173f, 0.70710678118654752440f, 0.92387953251128675613f };
+    constexpr float SIN_PI8[16] = { 0.0f, 0.38268343236508977173f, 0.70710678118654752440f, 0.92387953251128675613f, 1.0f, 0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f,
+                                    0.0f, -0.38268343236508977173f, -0.70710678118654752440f, -0.92387953251128675613f, -1.0f, -0.92387953251128675613f, -0.70710678118654752440f, -0.38268343236508977173f };
+    const int f0 = max(s0 - 3, 0);
+    if (f0 < p.frames) fetch(f0);
+    __syncthreads();                                     // the pass-2 twiddles are in LDS
+    auto emit_and_slide = [&](int seg) {
+        if (seg >= s0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { oL[(size_t)seg * SRT_HOP + tid + 256 * j] = acc[0][j].y; oR[(size_t)seg * SRT_HOP + tid + 256 * j] = acc[0][j].x; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j]; acc[3][j] = f2(0.0f, 0.0f);
+        }
+    };
+    for (int f = f0; f < s1; ++f) {
+        if (f < p.frames) {
+            // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; kept swapped (im, re): inverse-by-forward trick.  Bins k = tid + 256 j < 2048 are this
+            // thread's own transform inputs n2 = j; their partners 4096 - k go through `mir` to thread 256 - tid (slot 15 - j).
+            cf v[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = tid + 256 * j;
+                float wl = oob, wr = oob;
+                if (j < NM) { wl = k < p.F ? (has_mask ? gl[j] : 1.0f) : oob; wr = k < p.F ? (has_mask ? gr[j] : 1.0f) : oob; }
+                const cf A = sl[j] * wl, B = sr[j] * wr;                          // masked (re, im) of L and R
+                v[j] = sub_mi(B, A);                                              // (reR - imL, imR + reL)
+                mir[j * 256 + tid] = herm_hi(B, A);                               // (reR + imL, reL - imR)   (slot (0, 0) is never read)
+                if (j == 0 && tid == 0) v[0] = f2(B.x, A.x);                      // a[0] = re[0]           (stftFix.c:556-557)
+            }
+            if (tid == 0) {                                                       // rev[2048]: re - im wins (stftFix.c:563-566); F <= 2048, so bin 2048 is always out of band
+                const cf A = sl8 * oob, B = sr8 * oob;
+                mir[2048] = f2(B.x - B.y, A.x - A.y);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // all of this frame's rows have arrived: nothing below waits on the stores
+            if (f > f0) emit_and_slide(f - 1);
+            fetch(min(f + 1, p.frames - 1));             // next frame's rows fly under this transform
+            __syncthreads();                             // the mirror values are visible; every thread is past the previous frame's exchange 2
+#pragma unroll
+            for (int n2 = 8; n2 < 16; ++n2) v[n2] = mir[(15 - n2) * 256 + 256 - tid];
+            fft4096_1b(v, sx, w1, s_twb, tid);
+            asm volatile("" : "+v"(wc3), "+v"(ws3));     // keeps the 16 taps from being hoisted out of the frame loop (they would come back as 32 resident VGPRs)
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                // synthesis window tap of sample tid + 256 k2: (2/3) hann(i + 1/2) = 1/3 - (cos(th) cos(k2 pi/8) - sin(th) sin(k2 pi/8)) / 3 (stftFix.c:329-341)
+                const float pwk = fmaf(-wc3, COS_PI8[k2], fmaf(ws3, SIN_PI8[k2], 1.0f / 3.0f));
+                acc[k2 >> 2][k2 & 3] = __builtin_elementwise_fma(v[FFT16_AT(k2)], f2(pwk, pwk), acc[k2 >> 2][k2 & 3]);   // swapped back: L = .y, R = .x
+            }
+        } else if (f > f0) emit_and_slide(f - 1);
+    }
+    if (s1 > f0) emit_and_slide(s1 - 1);
+}
+
+int srt_launch_stft(const SrtStftParams& p, hipStream_t s)
+{
+    // short signals (one tile, the real-time regime): fewer frames per workgroup so that the frames spread over the CUs
+    int fpb = p.rows_total >= 4096 ? STFT_FPB : (p.rows_total >= 1024 ? 2 : 1);
+    if (p.rows_total >= 4096) {                          // whole rounds of the 768 resident workgroups (3 per CU), at most ~12 frames each
+        const int slots = 768, rounds = (p.rows_total + slots * 12 - 1) / (slots * 12);
+        fpb = (p.rows_total + slots * rounds - 1) / (slots * rounds);
+    }
+    const int blocks = (p.rows_total + fpb - 1) / fpb;
+    if (blocks <= 0) return 0;
+    SRT_LAUNCH(srt_stft_kernel, dim3(blocks), dim3(256), 0, s, p, fpb);
+    return srt_launch_status();
+}
+
 int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
 {
     if (p.frames <= 0) return 0;
     const int nseg = p.frames + 3;
     // One launch for all stems (blockIdx.y = stem): ~4 workgroups per CU over the whole grid when the stream is long enough,
     // runs of at least 13 segments so the 3-frame warm-up stays below ~25 % (64-tile batch, 4 stems: G = 65, 4.6 %).
-    int G = (int)(((size_t)nseg * p.nstems + 1023) / 1024);
+    // three-per-CU form: ONE round of the 768 resident workgroups (64-tile batch, 4 stems: G = 86, warm-up 3.5 %; two rounds measured the same, 1024 / 2304
+    // workgroups 6 % / 1 % slower); the two-per-CU form keeps its two rounds of 512
+    const int target = p.F > 1024 ? 1024 : 768;
+    int G = (int)(((size_t)nseg * p.nstems + target - 1) / target);
     const int gmin = (size_t)nseg * p.nstems >= 4096 ? 13 : 5;          // short signals: shorter runs (more warm-up, but all CUs busy)
     if (G < gmin) G = gmin;
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
-    SRT_LAUNCH(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    // F > 1024: eight mask registers per channel do not fit the 168-VGPR budget of the three-per-CU form (22 dwords would spill): the two-per-CU kernel
+    if (p.F > 1024) SRT_LAUNCH(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    else SRT_LAUNCH((srt_istft_ola3_kernel<4>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     return srt_launch_status();
 }
 
