@@ -195,15 +195,18 @@ def make_line(a, rec):
     per = {}
     for name, ms in tim:
         per.setdefault(name, []).append(ms)
-    avg = {k: float(np.mean(v)) for k, v in per.items()}
+    # per STEP: a layer that goes out as several launches (down1 of five sub-networks: a stack of four + one) counts with their sum
+    avg = {k: float(np.sum(v)) / a.steps for k, v in per.items()}
     inst = stems * a.tiles
     nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP or k == "actcopy")      # actcopy: the fallback bn+act pass in front of the first Winograd-form encoder layer (normally its producer writes the copy)
     nn_flop = FLOP_PER_PIXEL * T * F * inst
     # dominant kernel = the kernel SYMBOL with the largest share of the step (what tops rocprofv3 --stats);
     # achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the engine's stream)
-    layer_kernel = {}
+    layer_syms = {}
     for name, sym in kern:
-        assert layer_kernel.setdefault(name, sym) == sym, "launch %s ran on two kernels: %s / %s" % (name, layer_kernel[name], sym)
+        if sym not in layer_syms.setdefault(name, []):
+            layer_syms[name].append(sym)
+    layer_kernel = {k: " + ".join(v) for k, v in layer_syms.items()}           # (one symbol per layer, except a layer split into launch groups)
     sym_ms, sym_flop, sym_n = {}, {}, {}
     for k in avg:
         if k in LAYER_FLOP:

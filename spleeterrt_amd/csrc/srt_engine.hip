@@ -474,8 +474,21 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
             if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
-                p.stack = ns; p.CP2 = (ns * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
-                if (srt_launch_pack_stemstack(cbase + L.w, SRT_COEFF_STRIDE, ns, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
+                // more than four sub-networks (BASELINE configs[4]: five): the streamed down1 kernel stacks at most 4 x 16 rows, so the first whole groups of
+                // four go out here, each as its own stacked launch; the remainder (1..4 stems) follows the common path below
+                while (p.nstems > 4) {
+                    SrtConvParams q = p;
+                    q.nstems = 4; q.stack = 4; q.CP2 = 64; q.wpack2 = e->wpack2_d1; q.wpack2_stem = 0;
+                    if (srt_launch_pack_stemstack(q.wraw, SRT_COEFF_STRIDE, 4, e->wpack2_d1, L.cin, L.cout, q.CP2, e->stream)) return fail(-2, "pack launch failed");
+                    { TimerScope tg(e, "down1"); const int rg = srt_launch_enc2(q, e->stream); if (rg) return fail(-2, "encoder launch failed"); }
+                    p.nstems -= 4; p.elu_mask >>= 4;
+                    p.wraw += 4 * (size_t)SRT_COEFF_STRIDE; p.bias += 4 * (size_t)SRT_COEFF_STRIDE;
+                    if (p.bnShift) { p.bnShift += 4 * (size_t)SRT_COEFF_STRIDE; p.bnScale += 4 * (size_t)SRT_COEFF_STRIDE; }
+                    p.outRaw = eoff(e, p.outRaw, 4 * p.out_stem);
+                    if (p.outAct) p.outAct = eoff(e, p.outAct, 4 * p.out_stem);
+                }
+                p.stack = p.nstems; p.CP2 = (p.nstems * 16 + 63) / 64 * 64; p.wpack2 = e->wpack2_d1; p.wpack2_stem = 0;
+                if (srt_launch_pack_stemstack(p.wraw, SRT_COEFF_STRIDE, p.nstems, e->wpack2_d1, L.cin, L.cout, p.CP2, e->stream)) return fail(-2, "pack launch failed");
             }
             // Winograd form (down3..down6 of launches above 16 instances): reads the act(BN(raw)) copy of its input, writes raw + its own copy when
             // the next layer runs here too.  The first such layer's input copy is written by the direct layer in front (below); only when that layer

@@ -497,7 +497,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 // unit (instead of refetching the last ones as filler), and the next unit's first transformed patch comes out of the ordinary refills of the
 // last step, so a unit boundary is an epilogue and nothing else: no drained DMA queue, no extra barrier, no separate first transform.
 // NI: instances per workgroup (BA * BB * NI == 32 blocks): 1 for inputs of at least 4 x 32 pixels, 2 for 4 x 16 (up1: one instance is 16 blocks).
-template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0, int NI = 1, int PEEL = 0>   // PEEL 1: a unit's first K step starts from C = 0 instead of zeroed accumulators (measured slower here, faster in srt_dec_wino)
+// RB 1 (round 5): LDS bank discipline of the patch reads.  A lane's block columns are 2 floats apart, the four channels of a K step (kq) one channel pitch: with
+// the natural pitch of 240 floats (48 mod 64) the b64 of the middle columns and the two b32 of the outer ones are all 2-way conflicted (12 LDS cycles per row of a
+// 3-tap class).  RB 1 pads the pitch to 32 mod 64 floats (288: one more DMA piece per K step, still four DMA instructions per wave) and reads a row as THREE aligned
+// b64 pairs (columns b0-2..b0-1, b0..b0+1, b0+2..b0+3): within each 32-lane group kq 0 covers one half of the banks and kq 1 the other - 6 cycles, conflict-free.
+template <int BA, int BB, int ABL = 0, int UR = 3, int D = UR - 1, int BPS = 1, int SB = 0, int EA = 0, int ST = 0, int CS = 0, int NI = 1, int PEEL = 0, int RB = 1>   // PEEL 1: a unit's first K step starts from C = 0 instead of zeroed accumulators (measured slower here, faster in srt_dec_wino)
 __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(UR >= 3 && UR <= 5 && D >= BPS + EA && UR >= D + BPS && !(CS && EA), "rings (5 x 30 KiB = 150 KiB of LDS)");
@@ -506,8 +510,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
     constexpr int UBUF = 2 * UB1, NUP = 26;                                  // two M blocks (consecutive in the packed layout)
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;
-    constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
+    constexpr int PCH0 = NI * PH * PROW;                                     // floats of one channel's patch
+    constexpr int PCH = RB ? (PCH0 + 31) / 64 * 64 + 32 : PCH0;              // channel pitch in LDS (RB: the smallest value >= PCH0 that is 32 mod 64)
+    constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
     constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;                // DMA pieces per K step, per wave (the tail repeats the last piece)
+    static_assert(PCH >= PCH0 && PCH % 4 == 0 && NPIECE <= 8 * DPW, "patch pitch / piece map");
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
     __shared__ __attribute__((aligned(16))) float s_epi[96];                   // bias | BN scale | BN shift of the workgroup's 32 channels
     float* s_u = s_all;
@@ -575,9 +582,10 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
         const int tile0 = (unit / nsp) * NI, tx0 = sx_ * TW, ty0 = sy_ * TH;
         const int e = (lpiece - NUP) * 64 + lane;
-        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+        const int c = e / (PCH / 4), rem = e % (PCH / 4);                    // float4 `rem` of channel c's patch (rem >= PCH0 / 4: padding of the pitch)
+        const int j = rem % PR4, row = (rem / PR4) % PH, ii = rem / (PR4 * PH);
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
-        const bool ok = e >= 0 && e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const bool ok = e >= 0 && e < NF4 && rem < PCH0 / 4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
         const unsigned pvoff = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;   // srcA_tile == srcB_tile (launcher)
         return last_patch ? pvoff : (unsigned)(lpiece * 1024 + lane * 16);
     };
@@ -608,7 +616,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         if (i == DPW - 1) dma_flex(ku, ubuf, kp, pslot);
         else dma_u(i, ku, ubuf);
     };
-    const int poff = ((kq * NI + il) * PH + 2 * ba) * PROW + 2 * bb + 3;     // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
+    const int poff = kq * PCH + (il * PH + 2 * ba) * PROW + 2 * bb + 3;      // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
     const int aoff = (kq * 16 + l15) * WINO_LD;
     const int nk = p.Cin / 4;
     const int Wo = p.W << 1;
@@ -634,8 +642,13 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
         auto read_row = [&](const float* pbuf, int r) {
             const float* q = pbuf + poff + r * PROW;
             xm[r] = *reinterpret_cast<const float2*>(q + 1);
-            xa[r] = q[0];
-            if constexpr (X3) xb[r] = q[3];
+            if constexpr (RB) {                                              // the outer columns as halves of aligned b64 pairs (see RB above)
+                xa[r] = reinterpret_cast<const float2*>(q - 1)->y;
+                if constexpr (X3) xb[r] = reinterpret_cast<const float2*>(q + 3)->x;
+            } else {
+                xa[r] = q[0];
+                if constexpr (X3) xb[r] = q[3];
+            }
         };
         auto rows = [&](int r) {
             if constexpr (X3) wino_in3(xa[r], xm[r].x, xm[r].y, xb[r], t3[r]);
@@ -823,7 +836,15 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino32(const SrtConvParams p, 
 //   * the four classes ADD into the same 2 x 2 outputs, and they live in four different waves: at the end of a unit the waves exchange their
 //     classes' outputs through LDS (24 KiB per M block; the second M block borrows the U ring slot the unit has just finished with) and each
 //     lane finishes one of its four channels (+ bias -> raw, and act(BN(.)) -> the copy for the next layer): two barriers per unit.
-template <int BA, int BB, int NI, int ABL = 0, int PEEL = 0, int PR = 3>     // PEEL: as srt_dec_wino32.  PR: depth of the PATCH ring (patches PR - 1 K steps ahead; the U slabs stay two ahead in a ring of three)
+// RB 1 (round 5): LDS bank discipline of the patch reads.  A lane's block columns are 4 floats apart and the four channels of a K step (kq) sit one channel
+// pitch apart, so (MI355X_MICROARCH.md, LDS lane groups) a ds_read_b32 of the wave lands on 8 of 32 banks (4-way conflict: 8 LDS cycles for ONE value), and with
+// the natural pitch of 792 floats (24 mod 64) even the aligned ds_read_b128 of the middle columns is 2-way conflicted (its 16-lane groups mix kq 0 / kq 1).
+// RB 1 pads the channel pitch to a multiple of 64 floats - the DMA pieces per K step stay 13 (14): the padding lanes of the last piece fetch nothing - which
+// makes the b128 conflict-free, and takes each outer column as the half of an aligned ds_read_b64 (2-way: 4 cycles): 12 instead of 24 LDS cycles per patch row
+// of a 3-tap class, 8 instead of 16 for a 2-tap class.  MEASURED (r05b_tune): down3 / down4 / down5 0.751 / 0.638 / 0.572 ms against 0.738 / 0.631 / 0.562 with the
+// round-4 reads - the LDS pipe is not what these layers wait for, and the extra result registers cost more than the conflicts - so RB 0 stays the default here
+// (RB 2: the padded pitch alone, RB 3: the pairs alone; tuning builds, SRT_TUNE=encrb=1|2|3).  The same change is a 1 % gain in srt_dec_wino32, where it ships.
+template <int BA, int BB, int NI, int ABL = 0, int PEEL = 0, int PR = 3, int RB = 0>     // PEEL: as srt_dec_wino32.  PR: depth of the PATCH ring (patches PR - 1 K steps ahead; the U slabs stay two ahead in a ring of three)
 __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(BA * BB * NI == 32 && (BA * BB) % 16 == 0, "tile");
@@ -832,9 +853,11 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
     constexpr int UB1 = 4 * 16 * WINO_LD, UBUF = 2 * UB1, NUP = 26;
     constexpr int TH = 2 * BA, TW = 2 * BB;                                  // OUTPUT pixels per instance
     constexpr int PH = 4 * BA + 3, PROW = 4 * BB + 8, PR4 = PROW / 4;        // input patch
-    constexpr int PCH = NI * PH * PROW, NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;
+    constexpr int PCH0 = NI * PH * PROW;                                     // floats of one channel's patch
+    constexpr int PCH = (RB == 1 || RB == 2) ? (PCH0 + 63) / 64 * 64 : PCH0; // channel pitch in LDS (RB 1 / 2: a multiple of 64 floats)
+    constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4 of a K step's four channels; DMA pieces
     constexpr int NPIECE = NUP + NPP, DPW = (NPIECE + 7) / 8;
-    static_assert(DPW == 5 && NPP >= 7 && NPP <= 14, "piece map: per wave three U pieces, one U-or-patch piece, one patch piece");
+    static_assert(DPW == 5 && NPP >= 7 && NPP <= 14 && NPP == (PCH0 + 63) / 64, "piece map: per wave three U pieces, one U-or-patch piece, one patch piece (padding the pitch adds no piece)");
     constexpr int XBUF = 4 * 2 * 4 * 3 * 16 * 4;                             // class exchange of one M block: [writer class][group][kq][3 published channels][block][2 x 2 outputs] = 24 KiB
     static_assert(XBUF <= UBUF, "the second M block's exchange lives in a U ring slot");
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + PR * PBUF + XBUF];
@@ -894,9 +917,10 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         int sx_, sy_; wino_sp_xy(unit % nsp, tilesX, colrun, sx_, sy_);
         const int tile0 = (unit / nsp) * NI, tx0 = sx_ * BB, ty0 = sy_ * BA;     // tile origin in BLOCKS
         const int e = piece * 64 + lane;
-        const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+        const int c = e / (PCH / 4), rem = e % (PCH / 4);                    // float4 `rem` of channel c's patch (rem >= PCH0 / 4: padding of the pitch)
+        const int j = rem % PR4, row = (rem / PR4) % PH, ii = rem / (PR4 * PH);
         const int gy = 4 * ty0 - 1 + row, gx = 4 * tx0 - 4 + 4 * j;
-        const bool ok = piece >= 0 && e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+        const bool ok = piece >= 0 && e < NF4 && rem < PCH0 / 4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
         return ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;
     };
     auto unit_cur = [&](int unit) {
@@ -934,7 +958,7 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         else if (i == 3) dma_flex(ku, ubuf, kp, pslot);
         else dma_patch(kp, pslot);
     };
-    const int poff = ((kq * NI + il) * PH + 4 * ba) * PROW + 4 * bb + 3;     // this lane's block: patch rows +0..6, columns +0..6 (input column 4xb-1 first)
+    const int poff = kq * PCH + (il * PH + 4 * ba) * PROW + 4 * bb + 3;      // this lane's block: patch rows +0..6, columns +0..6 (input column 4xb-1 first)
     const int aoff = (kq * 16 + l15) * WINO_LD;
     const int nk = p.Cin / 4;
     const size_t ohw = (size_t)Ho * Wo;
@@ -962,7 +986,11 @@ __global__ void __launch_bounds__(512, 1) srt_enc_wino32(const SrtConvParams p, 
         auto read_row = [&](const float* pbuf, int r) {
             const float* b = pbuf + poff - 3 + (Y3 ? 2 * r : 2 * r + 1) * PROW;      // input column 4xb - 4: 16-byte aligned
             const float4 m = *reinterpret_cast<const float4*>(b + 4);
-            if constexpr (X3) { xr[r][0] = b[3]; xr[r][1] = m.y; xr[r][2] = m.w; xr[r][3] = b[9]; }
+            if constexpr (RB == 1 || RB == 3) {                              // outer columns as halves of aligned b64 pairs (see RB above)
+                const float2 hi2 = *reinterpret_cast<const float2*>(b + 8);
+                if constexpr (X3) { const float2 lo2 = *reinterpret_cast<const float2*>(b + 2); xr[r][0] = lo2.y; xr[r][1] = m.y; xr[r][2] = m.w; xr[r][3] = hi2.y; }
+                else { xr[r][0] = m.x; xr[r][1] = m.z; xr[r][2] = hi2.x; }
+            } else if constexpr (X3) { xr[r][0] = b[3]; xr[r][1] = m.y; xr[r][2] = m.w; xr[r][3] = b[9]; }
             else { xr[r][0] = m.x; xr[r][1] = m.z; xr[r][2] = b[8]; }
         };
         auto rows = [&](int r) {
@@ -1285,6 +1313,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 10: W32(0, 5, 3, 2, 1, 0, 1, 0);                                // the same without the continuous stream
         }
         if (wino_tune("winopeel=") == 1) W32(0, 3, 2, 1, 1, 0, 1, 1, 1, 1);            // the shipped arrangement with the first K step peeled (C = 0)
+        if (wino_tune("decrb=") == 0) { SRT_LAUNCH((srt_dec_wino32<2, 16, 0, 3, 2, 1, 1, 0, 1, 1, 1, 0, 0>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32)); return 0; }      // round-4 patch reads (natural pitch, b32 outer columns)
 #undef W32
 #endif
         SRT_LAUNCH((srt_dec_wino32<SRT_WINO32_SHIPPED>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32));
@@ -1366,6 +1395,11 @@ int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         }
         if (wino_tune("winopeel=") == 1) { SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
         if (wino_tune("winopr=") == 4) { SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 0, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
+        switch (wino_tune("encrb=")) {                                       // patch-read forms (RB): 1 padded pitch + b64 pairs, 2 padded pitch only, 3 b64 pairs only
+        case 1: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32)); return 0;
+        case 2: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 0, 3, 2>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32)); return 0;
+        case 3: SRT_LAUNCH((srt_enc_wino32<2, 16, 1, 0, 0, 3, 3>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32)); return 0;
+        }
 #endif
         SRT_LAUNCH((srt_enc_wino32<2, 16, 1>), dim3((unsigned)(wgs / tpw)), dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit() | wino_mfast_bit(u_stem * 4, p.Cout / 32));
     } else if (Ho >= 4 && Wo >= 16) {
