@@ -541,7 +541,9 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     // three-per-CU form: ONE round of the 768 resident workgroups (64-tile batch, 4 stems: G = 86, warm-up 3.5 %; two rounds measured the same, 1024 / 2304
     // workgroups 6 % / 1 % slower); the two-per-CU form keeps its two rounds of 512
     const int target = p.F > 1024 ? 1024 : 768;
-    int G = (int)(((size_t)nseg * p.nstems + target - 1) / target);
+    // (runs x stems must not exceed the resident workgroups: five stems at 768 / 5 = 153.6 runs would leave two workgroups for a second round)
+    const int max_runs = target / p.nstems > 0 ? target / p.nstems : 1;
+    int G = (nseg + max_runs - 1) / max_runs;
     const int gmin = (size_t)nseg * p.nstems >= 4096 ? 13 : 5;          // short signals: shorter runs (more warm-up, but all CUs busy)
     if (G < gmin) G = gmin;
     const int blocks = (nseg + G - 1) / G;

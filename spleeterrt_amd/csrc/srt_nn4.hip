@@ -195,7 +195,8 @@ constexpr int wino_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // UR = depth of the two LDS rings: U slab k lives in buffer k % UR and is issued UR - 1 K steps before its use, patch k in slot k % UR,
 // issued UR - 1 steps before the step that reads it (UR = 3 was the round-2 kernel).
 // CS 1: the units of a workgroup run as ONE stream of K steps (see srt_dec_wino32): no per-unit DMA drain, barrier or separate first transform.
-template <int BA, int BB, int NI, int ABL = 0, int UR = 3, int SB = 0, int CS = 0>   // SB 1: a quad's VALU work fenced behind its MFMAs (see srt_dec_wino32); ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
+// RB 1 (round 5): conflict-free patch reads - channel pitch padded to 32 mod 64 floats, a row read as three aligned b64 pairs (see srt_dec_wino32)
+template <int BA, int BB, int NI, int ABL = 0, int UR = 3, int SB = 0, int CS = 0, int RB = 1>   // SB 1: a quad's VALU work fenced behind its MFMAs (see srt_dec_wino32); ABL (SRT_TUNING builds): timing ablations with wrong results - 1 no barrier, 2 no patch DMA, 3 no U DMA, 4 no transform, 5 no A reads
 __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, const float* __restrict__ U, size_t u_stem, int tpw)
 {
     static_assert(UR >= 3 && UR <= 6, "ring depth");
@@ -203,9 +204,11 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
     constexpr int UBUF = 4 * 16 * WINO_LD;                                   // 3328 floats = 13 KiB = 13 DMA pieces
     constexpr int TH = 2 * BA, TW = 2 * BB;
     constexpr int PH = TH + 2, PROW = TW + 8, PR4 = PROW / 4;                // patch: PH rows of PROW floats per (channel, instance)
-    constexpr int PCH = NI * PH * PROW;                                      // floats per channel
+    constexpr int PCH0 = NI * PH * PROW;                                     // floats of one channel's patch
+    constexpr int PCH = RB ? (PCH0 + 31) / 64 * 64 + 32 : PCH0;              // channel pitch in LDS (RB: the smallest value >= PCH0 that is 32 mod 64)
     constexpr int NF4 = PCH, NPP = (NF4 + 63) / 64, PBUF = NPP * 256;        // float4s (4 channels), DMA pieces and floats per patch buffer
     constexpr int PPW = (NPP + 7) / 8;                                       // patch pieces per wave
+    static_assert(PPW == ((PCH0 + 63) / 64 + 7) / 8, "padding the pitch adds no DMA instruction");
     __shared__ __attribute__((aligned(16))) float s_all[UR * UBUF + UR * PBUF];
     float* s_u = s_all;
     float* s_p = s_all + UR * UBUF;
@@ -261,9 +264,10 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = min(wave + 8 * i, NPP - 1), e = piece * 64 + lane;
-            const int j = e % PR4, row = (e / PR4) % PH, ii = (e / (PR4 * PH)) % NI, c = e / (PR4 * PH * NI);
+            const int c = e / (PCH / 4), rem = e % (PCH / 4);                // float4 `rem` of channel c's patch (rem >= PCH0 / 4: padding of the pitch)
+            const int j = rem % PR4, row = (rem / PR4) % PH, ii = rem / (PR4 * PH);
             const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * j;
-            const bool ok = e < NF4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
+            const bool ok = e < NF4 && rem < PCH0 / 4 && tile0 + ii < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx + 3 < p.W;
             pvoff[i] = ok ? 4u * (unsigned)((size_t)ii * p.srcA_tile + (size_t)c * hw + (size_t)gy * p.W + gx) : OOR;  // srcA_tile == srcB_tile (launcher)
         }
         pa = p.srcA + stem * p.srcA_stem + tile0 * p.srcA_tile;
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         const unsigned dst = pm0[i] + (unsigned)slot * (unsigned)(PBUF * 4);
         asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(pvoff[i]), "s"(rs), "s"(dst), "s"(soff) : "memory");
     };
-    const int poff = ((kq * NI + il) * PH + 2 * ba) * PROW + 2 * bb + 3;     // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
+    const int poff = kq * PCH + (il * PH + 2 * ba) * PROW + 2 * bb + 3;      // this lane's patch: rows +0..3, columns +0..3 (b0-1..b0+2)
     const int aoff = (kq * 16 + l15) * WINO_LD;
     const int nk = p.Cin / 4;
     const int Wo = p.W << 1;
@@ -332,7 +336,8 @@ __global__ void __launch_bounds__(512, 1) srt_dec_wino(const SrtConvParams p, co
         auto read_row = [&](const float* pbuf, int r) {
             const float* q = pbuf + poff + r * PROW;
             xm[r] = *reinterpret_cast<const float2*>(q + 1);
-            xo[r] = make_float2(q[0], q[3]);
+            if constexpr (RB) xo[r] = make_float2(reinterpret_cast<const float2*>(q - 1)->y, reinterpret_cast<const float2*>(q + 3)->x);
+            else xo[r] = make_float2(q[0], q[3]);
         };
         auto rows = [&](int r) {
             wino_in3(xo[r].x, xm[r].x, xm[r].y, xo[r].y, t3[r]);
@@ -1331,6 +1336,7 @@ int srt_launch_dec_wino(const SrtConvParams& p, const float* U, size_t u_stem, h
         case 4: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 4>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         case 5: SRT_LAUNCH((srt_dec_wino<4, 16, 1, 5>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0;
         }
+        if (wino_tune("dec16rb=") == 0) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 0, 0, 0>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }      // round-4 patch reads
         if (wino_tune("winosb=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
         if (wino_tune("winocs=") == 1) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 3, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
         if (wino_tune("winocs=") == 2) { SRT_LAUNCH((srt_dec_wino<4, 16, 1, 0, 4, 0, 1>), grid, dim3(512), 0, s, p, U, u_stem, tpw | wino_walk_bit()); return 0; }
