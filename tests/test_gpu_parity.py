@@ -572,6 +572,31 @@ def test_config4_five_stems_fp16_end_to_end(oracle, coeffs, prec, mask_tol, stem
     eng.close()
 
 
+@pytest.mark.parametrize("modes,ntiles,F", [((1, 0, 1, 1, 0), 2, 512), ((1, 0, 1, 1, 0, 1), 2, 512), ((1, 1, 0, 1, 1), 48, 1024)])
+def test_more_than_four_stems_down1_groups(oracle, coeffs, modes, ntiles, F):
+    """Five and six sub-networks in fp32 (round 5): down1 goes out as stacked groups of four stems + the remainder (4 + 1, 4 + 2), each group with its own
+    slice of weights, bias, outputs and activation bits.  Mixed LeakyReLU / ELU stems so that a wrong shift of the activation mask shows; the 48-tile case
+    puts the first group on the streamed down1 kernel (8 column strips x 48 tiles = 384 workgroups) and the remainder on the tiled one.  Every tensor of
+    the checked instances against the oracle (spleeter.c:182-300)."""
+    import torch
+    import spleeterrt_amd as srt
+    T, S = 64, len(modes)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles)
+    cs = [coeffs(s) for s in range(S)]                           # seeds 2024 + stem: every sub-network has its own weights
+    for s in range(S):
+        eng.set_coeff(s, cs[s])
+    x = _mag_input(oracle, ntiles, T, F, seed=909)
+    masks = eng.forward(torch.from_numpy(x).cuda())
+    kern = None
+    if ntiles >= 48:
+        eng.set_timing(True); eng.forward(torch.from_numpy(x).cuda(), masks); kern = [k for n, k in eng.get_timing_kernels() if n == "down1"]; eng.set_timing(False)
+        assert len(kern) == 2 and kern[0].startswith("srt_down1_stream_kernel") and kern[1].startswith("srt_enc_mfma2"), kern
+    masks = masks.cpu().numpy()
+    for s, t in ((0, 0), (3, ntiles - 1), (4, 0), (S - 1, ntiles - 1), (1, ntiles // 2)):
+        _check_taps(eng, oracle, cs[s], x[t], modes[s], s, t, masks=masks, tag="%d stems" % S)
+    eng.close()
+
+
 @pytest.mark.parametrize("stems", [2, 3])
 def test_cli_flow_device_resident(oracle, coeffs, stems):
     """srtSeparateCli == the offline CLI's flow restated over the oracle (main.c:776-798 two outputs with the time-domain
