@@ -339,6 +339,16 @@ def make_line(a, rec):
     return res
 
 
+def flush_c_stdio():
+    """librccl prints its version banner through C stdio, which is block-buffered when stdout is a pipe or a file: unflushed, it would land AFTER the JSON line at
+    process exit.  The driver reads one JSON line from stdout - it has to be the last thing written."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -421,6 +431,7 @@ def measure_ranks(a, stems):
         if dist_on:
             dist.broadcast(w, 0)
         eng.set_coeff(s, w)
+    flush_c_stdio()                                          # (RCCL's banner, printed by the first collective, goes out now - not after the JSON line)
     n = a.tiles * T * HOP
     g = torch.Generator(device=dev).manual_seed(777 + rank)
     L = (torch.rand(n, device=dev, generator=g) - 0.5) * 0.2
@@ -561,12 +572,14 @@ def main():
                     "config": {"workload": res["config"], "tiles_per_rank": res["tiles_per_rank"], "max_tiles_per_chunk": res["max_tiles_per_chunk"],
                                "parallelism": "tile-range partition x%d, weight broadcast only" % res["n_gpus"]},
                     "c4": res}
-            print(json.dumps(line))
+            flush_c_stdio()
+            print(json.dumps(line), flush=True)
         return
 
     rec = measure_native(a, a.stems) if a.host == "native" else measure_ranks(a, a.stems)
+    flush_c_stdio()
     if rec is not None:
-        print(json.dumps(make_line(a, rec)))
+        print(json.dumps(make_line(a, rec)), flush=True)
 
 
 if __name__ == "__main__":

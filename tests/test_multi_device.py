@@ -76,6 +76,7 @@ def test_native_host_bench_line_equals_the_per_process_line():
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "3", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stdout.strip().splitlines()[-1].startswith("{"), r.stdout[-600:]      # the JSON line is the LAST thing on stdout (librccl's banner is flushed before it)
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     best = None
     for _ in range(3):

@@ -35,6 +35,8 @@ def _launch(args, distributed):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines, r.stdout[-2000:] + r.stderr[-2000:]
+    if args[0] == "bench.py":                                # the driver reads ONE JSON line: nothing (RCCL's version banner comes through C stdio) may follow it
+        assert r.stdout.strip().splitlines()[-1] == lines[-1], r.stdout[-600:]
     return json.loads(lines[-1])
 
 
