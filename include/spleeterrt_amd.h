@@ -34,7 +34,9 @@ extern "C" {
 #define SRT_IMPL_NAIVE  1   /* one-thread-per-output HIP kernels (debug cross-check, still GPU) */
 #define SRT_PREC_F32    0   /* v_mfma_f32_32x32x2_f32: exact fp32 products (default; the headline path) */
 #define SRT_PREC_F16    1   /* v_mfma_f32_32x32x16_f16, activations rounded to fp16 (BASELINE configs[4]; mask tolerance 2e-2) */
-#define SRT_PREC_F16X2  2   /* same MFMA, activations split hi+lo: products exact in fp32 when the weights are fp16-representable */
+#define SRT_PREC_F16X2  2   /* same MFMA, activations split hi+lo: products exact in fp32 BECAUSE the weights are fp16 values - srtSetCoeff* checks
+                             * every conv weight of the blob and refuses (-5, srtLastError names the count) one that the fp16 pack would round, e.g. a raw
+                             * fp32 .dat blob with 24-bit mantissas: nothing is rounded silently in this mode */
 
 typedef struct srt_engine srt_engine;
 

@@ -70,7 +70,11 @@ void initSpleeter(struct _spleeter* nn, size_t width, size_t height, int stemMod
     cfg.variant = env_variant(); cfg.max_tiles = 1; cfg.impl = SRT_IMPL_MFMA; cfg.precision = env_precision();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { compat_fail("initSpleeter", "no HIP device (this library has no CPU path)"); return; }
-    if (!hip_ok(hipStreamCreateWithFlags(&nn->stream, hipStreamNonBlocking), "initSpleeter")) { nn->stream = nullptr; return; }
+    // lowest stream priority: a tile-API instance is a throughput caller; the real-time surface's per-hop stream (csrc/srt_stream.hip) runs at the
+    // highest, so a plugin instance sharing the GPU with tile-API workers is dispatched ahead of their queued network kernels
+    int prLeast = 0, prGreatest = 0;
+    if (!hip_ok(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest), "initSpleeter")) return;
+    if (!hip_ok(hipStreamCreateWithPriority(&nn->stream, hipStreamNonBlocking, prLeast), "initSpleeter")) { nn->stream = nullptr; return; }
     if (srtCreate(&cfg, nn->stream, &nn->eng)) { nn->eng = nullptr; compat_fail("initSpleeter", nullptr); return; }
     if (srtSetCoeffHost(nn->eng, 0, coeff)) { compat_fail("initSpleeter(weights)", nullptr); return; }
     srtSetGraphMode(nn->eng, 1);                              // every processSpleeter call repeats the same launch sequence on d_x / d_y

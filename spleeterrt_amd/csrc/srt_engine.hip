@@ -297,8 +297,35 @@ void srtDestroy(srt_engine* e)
     delete e;
 }
 
+// SRT_PREC_F16X2 promises fp32-level parity, which holds only while every weight that goes through the fp16 pack is an fp16 value: refuse a blob that
+// is not (the caller picks SRT_PREC_F32, or SRT_PREC_F16 with its 2e-2 tolerance class, knowingly) instead of silently rounding it.
+static int check_f16x2_weights(srt_engine* e, int stem)
+{
+    unsigned* d_count = nullptr; unsigned bad = 0; size_t total = 0;
+    HIPCHK(hipMalloc((void**)&d_count, sizeof(unsigned)));
+    hipError_t er = hipMemsetAsync(d_count, 0, sizeof(unsigned), e->stream);
+    const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
+    for (int i = 0; i < 6 && er == hipSuccess; ++i) {
+        const LayerOff& D = e->lo.down[i]; const LayerOff& U = e->lo.up[i];
+        if (e->wpack16_down[i]) { total += (size_t)25 * D.cin * D.cout; if (srt_launch_count_not_fp16(c + D.w, (size_t)25 * D.cin * D.cout, d_count, e->stream)) er = hipErrorLaunchFailure; }
+        if (e->wpack16_up[i]) { total += (size_t)25 * U.cin * U.cout; if (srt_launch_count_not_fp16(c + U.w, (size_t)25 * U.cin * U.cout, d_count, e->stream)) er = hipErrorLaunchFailure; }
+    }
+    if (er == hipSuccess) er = hipMemcpyAsync(&bad, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    hipFree(d_count);
+    HIPCHK(er);
+    if (bad) {
+        e->have_coeff[stem] = false;
+        char what[96];
+        snprintf(what, sizeof what, "sub-network %d: %u of %zu are not and would be rounded", stem, bad, total);
+        return fail(-5, "srtSetCoeff: SRT_PREC_F16X2 needs fp16-representable conv weights (%s); use SRT_PREC_F32, or SRT_PREC_F16 for the fp16 tolerance class", what);
+    }
+    return 0;
+}
+
 static int pack_stem(srt_engine* e, int stem)
 {
+    if (e->cfg.precision == SRT_PREC_F16X2 && e->cfg.impl == SRT_IMPL_MFMA) { const int rc = check_f16x2_weights(e, stem); if (rc) return rc; }
     for (int i = 0; i < 6; ++i) {
         const LayerOff& D = e->lo.down[i]; const LayerOff& U = e->lo.up[i];
         const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;

@@ -107,6 +107,7 @@ int  srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, h
 int  srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s);
+int  srt_launch_count_not_fp16(const float* w, size_t n, unsigned* d_count, hipStream_t s);   // weights the fp16 pack would round (SRT_PREC_F16X2 guard)
 int  srt_set_sigmoid_table(const float* tbl1026);
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);
 // Winograd decoder kernels (srt_nn4.hip): U = transformed weights [Cin/4][Cout/16][4][16][52] per stem; the launcher returns 1

@@ -38,6 +38,24 @@ int srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP,
     return srt_launch_status();
 }
 
+// SRT_PREC_F16X2 keeps fp32-level accuracy only when every conv weight IS an fp16 value (the Executable's container, main.c:423-443); the VST's raw fp32
+// .dat blobs (PluginProcessor.cpp:47-61) need not be.  One pass over a layer's weights counting those that the pack above would round.
+__global__ void srt_count_not_fp16_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ count)
+{
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        bad += ((float)(_Float16)v != v) ? 1u : 0u;           // NaN counts as not representable too
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+int srt_launch_count_not_fp16(const float* w, size_t n, unsigned* d_count, hipStream_t s)
+{
+    SRT_LAUNCH(srt_count_not_fp16_kernel, dim3(512), dim3(256), 0, s, w, n, d_count);
+    return srt_launch_status();
+}
+
 __device__ __forceinline__ void srt_dma16h(const _Float16* gsrc, _Float16* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -126,8 +126,14 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
 #define INITTRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { stream_fail("Spleeter4StemsInit", hipGetErrorString(_e)); return; } } while (0)
         // non-blocking streams: no implicit ordering against the legacy null stream, so another instance's (another host thread's) synchronous
         // copies and memsets during ITS Init can neither stall this instance's hops nor invalidate the graph capture of this one's pre-warm
-        INITTRY(hipStreamCreateWithFlags(&s->hop, hipStreamNonBlocking));
-        INITTRY(hipStreamCreateWithFlags(&s->nn, hipStreamNonBlocking));
+        // Priorities: the per-hop stream (one forward + eight inverse FFTs the audio callback WAITS for) gets the device's highest priority, the
+        // network stream (four U-Nets joined only every T hops) the lowest - the reference gives the per-hop iFFT its own thread and joins the
+        // network threads every T hops (Spleeter4Stems.c:351-371).  With several plugin instances on one GPU a hop's kernels are then dispatched
+        // ahead of every instance's queued network kernels instead of waiting their turn behind them.
+        int prLeast = 0, prGreatest = 0;
+        INITTRY(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+        INITTRY(hipStreamCreateWithPriority(&s->hop, hipStreamNonBlocking, prGreatest));
+        INITTRY(hipStreamCreateWithPriority(&s->nn, hipStreamNonBlocking, prLeast));
         INITTRY(hipEventCreateWithFlags(&s->evMag, hipEventDisableTiming));
         INITTRY(hipEventCreateWithFlags(&s->evNN, hipEventDisableTiming));
         srt_config cfg; memset(&cfg, 0, sizeof cfg);

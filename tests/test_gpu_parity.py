@@ -536,6 +536,39 @@ def test_fp16_mfma_variants(oracle, coeffs, prec, mask_tol, T, F):
     eng.close()
 
 
+def test_f16x2_refuses_weights_that_are_not_fp16_values(oracle, coeffs):
+    """SRT_PREC_F16X2 promises the fp32 tolerance, which holds only while every conv weight IS an fp16 value (the Executable's container, main.c:423-443).  A raw
+    fp32 blob with 24-bit mantissas (the VST's .dat files may hold those, PluginProcessor.cpp:47-61) is refused at srtSetCoeff* with a message instead of being rounded
+    silently - through every entry form (host, device) - and the engine keeps refusing srtForward for that sub-network; the same blob is accepted in f32 and in f16 (whose
+    tolerance class says so), and an fp16-representable blob is accepted in f16x2 and still meets the fp32 tolerance."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F = 64, 512
+    good = coeffs(0)
+    rng = np.random.default_rng(5)
+    bad = (good * (1.0 + rng.uniform(-3e-4, 3e-4, good.shape))).astype(np.float32)          # 24-bit mantissas
+    assert np.any(bad.astype(np.float16).astype(np.float32) != bad)
+    eng = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1, precision=srt.PREC_F16X2)
+    x = _mag_input(oracle, 1, T, F, seed=31)
+    for setter in (lambda w: eng.set_coeff(0, w), lambda w: eng.set_coeff(0, torch.from_numpy(w).cuda())):
+        with pytest.raises(srt.EngineError, match="fp16-representable"):
+            setter(bad)
+        with pytest.raises(srt.EngineError, match="weights not set"):
+            eng.forward(torch.from_numpy(x).cuda())
+    eng.set_coeff(0, good)                                    # a representable blob afterwards: accepted, fp32-level parity
+    m = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    y = oracle.forward(good, x[0], 1, oracle.VARIANT_VST)
+    assert float(np.abs(m[0, 0] - y).max()) <= MASK_TOL_EXACT
+    eng.close()
+    for prec, tol in ((srt.PREC_F32, MASK_TOL_EXACT), (srt.PREC_F16, 2e-2)):                # the other modes take the same blob
+        e2 = _engine(F=F, T=T, stem_modes=(1,), variant=srt.VARIANT_VST, max_tiles=1, precision=prec)
+        e2.set_coeff(0, bad)
+        m = e2.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+        y = oracle.forward(bad, x[0], 1, oracle.VARIANT_VST)
+        assert float(np.abs(m[0, 0] - y).max()) <= tol
+        e2.close()
+
+
 @pytest.mark.parametrize("prec,mask_tol,stem_tol", [("f16", 2e-2, 1e-2), ("f16x2", MASK_TOL_EXACT, 1e-4)])
 def test_config4_five_stems_fp16_end_to_end(oracle, coeffs, prec, mask_tol, stem_tol):
     """BASELINE configs[4] as named: 5 stems (the fifth = one more spleeterCoeff blob), T=256, F=1024, fp16-MFMA conv

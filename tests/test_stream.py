@@ -48,4 +48,4 @@ def test_streaming_matches_reference(oracle, coeffs, T, F, chunks):
         err = np.sqrt(np.mean((tail_g[j] - tail_r[j]) ** 2)) / (np.sqrt(np.mean(tail_r[j] ** 2)) + 1e-30)
         assert err <= 1e-4, "component %d rel rms %g" % (j, err)
     assert np.abs(tail_g - tail_r).max() <= 1e-4 * np.abs(tail_r).max()
-    assert np.all(got[2:4, 2 * T * 1024:][:, :] == got[2:4, 2 * T * 1024:])               # finite
+    assert np.isfinite(got).all() and np.isfinite(ref).all()
