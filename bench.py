@@ -63,7 +63,7 @@ def same_kernel(a, b):
 
 def is_f16_kernel(symbol):
     """kernels of csrc/srt_nn3.hip (v_mfma_f32_32x32x16_f16), and up6 - tiled or streamed - when its inputs are halves (4th template argument)"""
-    if "_f16<" in symbol:
+    if "_f16<" in symbol or "_c8<" in symbol:          # csrc/srt_nn3.hip, and the C8-form kernels of csrc/srt_nn5.hip (same MFMA)
         return True
     if symbol.startswith("srt_up6_kernel<") or symbol.startswith("srt_up6_stream_kernel<"):
         args = symbol.split("<", 1)[1].rstrip("> ").split(",")
@@ -75,6 +75,8 @@ def executed_fraction(symbol, precision="f32"):
     """MFMA products the kernel executes / products of the layer's algorithm (the reference's direct convolution)"""
     if "wino" in symbol:
         return WINO_EXECUTED_FRACTION
+    if symbol.startswith("srt_dec_c8<") and symbol.rstrip("> ").endswith("true"):
+        return 15.0 * 32 / (25.0 * 16)      # up5, class-stacked: 15 products of 32 rows (2 x-classes x 16 channels) where the algorithm has 25 of 16 rows
     if precision == "f16x2" and "_f16<" in symbol:
         return 2.0                          # activations split hi + lo: two MFMAs per tap
     return 1.0

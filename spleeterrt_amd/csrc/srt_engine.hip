@@ -46,6 +46,7 @@ static const int ENC_CH[6][2] = { {2, 16}, {16, 32}, {32, 64}, {64, 128}, {128, 
 static const int DEC_CH[6][2] = { {512, 256}, {512, 128}, {256, 64}, {128, 32}, {64, 16}, {32, 1} };
 
 struct LayerOff { size_t w, b, bn; int cin, cout, cp; };
+#define SRT_W16CS_U5 ((size_t)(64 / 16) * 15 * 2 * 32 * 8)    // halves per stem of up5's class-stacked fp16 weights
 struct Layout { LayerOff down[6], up[6]; size_t head_w, head_b, total; };
 
 static Layout make_layout()
@@ -114,6 +115,8 @@ struct srt_engine {
     size_t raw_tile[6], up_tile[6];                    // elements per instance
     float* act16buf[5];                                // fp16-storage mode only: act(bn(raw_i)) as halves, written by the producer
     bool act16;                                        // raw[0..5] and up[0..4] hold IEEE halves (precision F16 on a supported geometry)
+    uint16_t* wpack16cs_u5;                            // act16 only: up5's class-stacked fp16 weights [n_stems][4][15][2][32][8] (srt_nn5.hip)
+    bool last_c8;                                      // the last forward stored raw2..6 / act2..5 / up1..4 channel-interleaved by eight (srt_nn5.hip): srtCopyTensor's view
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
     // DSP
@@ -182,6 +185,7 @@ static void free_all(srt_engine* e)
     if (e->ws) hipFree(e->ws);
     if (e->wpack2_d1) hipFree(e->wpack2_d1);
     if (e->wpack2_u5) hipFree(e->wpack2_u5);
+    if (e->wpack16cs_u5) hipFree(e->wpack16cs_u5);
     for (int i = 0; i < 6; ++i) { if (e->wino_u[i]) hipFree(e->wino_u[i]); if (e->wino_e[i]) hipFree(e->wino_e[i]); if (e->act32[i]) hipFree(e->act32[i]); }
     for (int i = 0; i < 6; ++i) { if (e->wpack_down[i]) hipFree(e->wpack_down[i]); if (e->wpack_up[i]) hipFree(e->wpack_up[i]); }
     for (int i = 0; i < 6; ++i) { if (e->raw[i]) hipFree(e->raw[i]); if (e->up[i]) hipFree(e->up[i]); if (i < 5 && e->act16buf[i]) hipFree(e->act16buf[i]); }
@@ -207,6 +211,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
     memset(e->wino_e, 0, sizeof e->wino_e); memset(e->wino_e_stem, 0, sizeof e->wino_e_stem); memset(e->act32, 0, sizeof e->act32);
+    e->wpack16cs_u5 = nullptr; e->last_c8 = false;
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -253,6 +258,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     // fp16 activation storage: every layer between down1 and up6 must run on the fp16-MFMA kernels, which stage aligned
     // 4-pixel row segments at every level (up1's input is F/64 wide): F % 256 == 0.  Other geometries keep fp32 tensors.
     e->act16 = cfg->precision == SRT_PREC_F16 && cfg->impl == SRT_IMPL_MFMA && cfg->F % 256 == 0;
+    if (e->act16 && hipMalloc((void**)&e->wpack16cs_u5, S * SRT_W16CS_U5 * 2) != hipSuccess) { free_all(e); delete e; return fail(-2, "srtCreate: hipMalloc failed"); }
     for (int i = 0; i < 6; ++i) {
         e->raw_tile[i] = (size_t)ENC_CH[i][1] * (HW >> (2 * (i + 1)));
         EALLOC(e->raw[i], (S * NT * e->raw_tile[i] + (e->act16 ? 1 : 0)) / (e->act16 ? 2 : 1));
@@ -337,6 +343,8 @@ static int pack_stem(srt_engine* e, int stem)
         if (e->wino_e[i] && srt_launch_pack_wino_enc(c + D.w, e->wino_e[i] + stem * e->wino_e_stem[i], D.cin, D.cout, e->stream)) return fail(-2, "pack launch failed");
     }
     if (srt_launch_pack_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack2_u5 + (size_t)stem * 64 * 15 * 32, 64, 16, e->stream))
+        return fail(-2, "pack launch failed");
+    if (e->wpack16cs_u5 && srt_launch_pack16_classstack(e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE + e->lo.up[4].w, e->wpack16cs_u5 + (size_t)stem * SRT_W16CS_U5, 64, 16, e->stream))
         return fail(-2, "pack launch failed");
     e->have_coeff[stem] = true;
     return 0;
@@ -461,6 +469,11 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     // Winograd-form layers whenever the layer geometry fits, whatever the batch - the same bits for a tile in any batch.
     const bool few = (size_t)ns * ntiles <= 16 && !e->cfg.batch_invariant;
     const bool small = few && e->ws;
+    // fp16 storage, launches above 16 instances: the tensors between down2 and up5 are kept channel-interleaved by eight and the layers run on the DMA-fed
+    // kernels of srt_nn5.hip (SPLEETERRT_C8=0: the planar kernels of srt_nn3.hip everywhere, for A/B runs)
+    static const bool c8_env = []() { const char* v = getenv("SPLEETERRT_C8"); return !(v && v[0] == '0'); }();
+    const bool c8 = e->act16 && !few && c8_env;
+    e->last_c8 = c8;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
         unsigned elu_mask = 0;
@@ -556,7 +569,13 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_down[i]) {
                 p.wpack16 = e->wpack16_down[i] + (size_t)s0 * e->wpack16_down_stem[i]; p.wpack16_stem = e->wpack16_down_stem[i];
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
-                rc2 = srt_launch_enc_f16(p, e->stream);
+                if (c8 && i >= 2) {                                             // C8 in, C8 out (srt_nn5.hip)
+                    rc2 = srt_launch_enc_c8(p, e->stream);
+                    if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for an encoder layer");
+                } else {
+                    p.c8out = c8 && i == 1;                                     // down2: planar input (down1's act copy), C8 outputs
+                    rc2 = srt_launch_enc_f16(p, e->stream);
+                }
             }
             if (e->act16 && i > 0 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for an encoder layer");
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) { rc2 = srt_launch_enc2(p, e->stream); if (rc2 == 0 && producer_copy) act_ready = true; }
@@ -591,7 +610,11 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             if (e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_up[i]) {
                 p.wpack16 = e->wpack16_up[i] + (size_t)s0 * e->wpack16_up_stem[i]; p.wpack16_stem = e->wpack16_up_stem[i];
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
-                rc2 = srt_launch_dec_f16(p, e->stream);
+                if (c8 && i < 5) {                                              // C8 in; C8 out (up1..up4) or planar out (up5, class-stacked weights)
+                    p.wpack16cs = e->wpack16cs_u5 + (size_t)s0 * SRT_W16CS_U5; p.wpack16cs_stem = SRT_W16CS_U5;
+                    rc2 = srt_launch_dec_c8(p, e->stream);
+                    if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for a decoder layer");
+                } else rc2 = srt_launch_dec_f16(p, e->stream);
             }
             if (e->act16 && i < 5 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for a decoder layer");
             if (rc2 == 1 && e->wino_u[i] && (!few || srt_wino_force())) rc2 = srt_launch_dec_wino(p, e->wino_u[i] + (size_t)s0 * e->wino_u_stem[i], e->wino_u_stem[i], e->stream);
@@ -1038,14 +1061,25 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     const bool halves = e->act16 && !(name[0] == 'u' && idx == 5);           // up6 (the head's input) is always fp32
     const float* src = halves ? eoff(e, const_cast<float*>(base), ((size_t)stem * e->last_ntiles + tile) * per) : base + ((size_t)stem * e->last_ntiles + tile) * per;
     float* tmp = nullptr;
+    // raw2..raw6 (and the act taps derived from them) and up1..up4 of a large fp16-storage batch are channel-interleaved by eight (srt_nn5.hip): the tap
+    // is returned planar, like every other
+    const bool c8 = halves && e->last_c8 && ((name[0] == 'u') ? idx <= 3 : idx >= 1);
+    float* planar = nullptr;
+    if (c8) {
+        const int C = name[0] == 'u' ? DEC_CH[idx][1] : ENC_CH[idx][1];
+        HIPCHK(hipMalloc((void**)&planar, per * sizeof(float)));
+        if (srt_launch_c8_to_float(src, planar, C, per / C, e->stream)) { hipFree(planar); return fail(-2, "conversion launch failed"); }
+        src = planar;
+    }
+    const bool halves_in = halves && !c8;
     if (derived) {
         // "actN" is no longer stored: the next encoder layer applies act(bn(convN)) while staging.  Materialise it for the tap.
         const LayerOff& L = e->lo.down[idx];
         const float* c = e->coeff_all + (size_t)stem * SRT_COEFF_STRIDE;
         HIPCHK(hipMalloc((void**)&tmp, per * sizeof(float)));
-        if (srt_launch_bn_act(src, halves, tmp, c + L.bn + L.cout, c + L.bn, L.cout, per / L.cout, e->cfg.stem_mode[stem] ? SRT_ACT_ELU : SRT_ACT_LEAKY, e->cfg.variant, e->stream)) { hipFree(tmp); return fail(-2, "bn-act launch failed"); }
+        if (srt_launch_bn_act(src, halves_in, tmp, c + L.bn + L.cout, c + L.bn, L.cout, per / L.cout, e->cfg.stem_mode[stem] ? SRT_ACT_ELU : SRT_ACT_LEAKY, e->cfg.variant, e->stream)) { hipFree(tmp); if (planar) hipFree(planar); return fail(-2, "bn-act launch failed"); }
         src = tmp;
-    } else if (halves) {
+    } else if (halves_in) {
         HIPCHK(hipMalloc((void**)&tmp, per * sizeof(float)));
         if (srt_launch_half_to_float(src, tmp, per, e->stream)) { hipFree(tmp); return fail(-2, "conversion launch failed"); }
         src = tmp;
@@ -1053,6 +1087,7 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     hipError_t er = hipStreamSynchronize(e->stream);
     if (er == hipSuccess) er = hipMemcpy(h_dst, src, per * sizeof(float), hipMemcpyDeviceToHost);
     if (tmp) hipFree(tmp);
+    if (planar) hipFree(planar);
     HIPCHK(er);
     return 0;
 }

@@ -74,6 +74,11 @@ struct SrtConvParams {
     // (out16) hold IEEE halves instead of floats - same planar layout, same strides IN ELEMENTS, half the HBM bytes.  The
     // pointers keep their float type in this struct; kernels that honour the flags reinterpret them.
     int in16, out16;
+    // Large fp16-storage batches (round 6, srt_nn5.hip): the tensors between down2 and up5 are channel-interleaved by eight ("C8": element (c, y, x) at
+    // ((c/8) H W + y W + x) 8 + c % 8 - the B-fragment layout of the fp16 MFMA, so patches go HBM -> LDS by DMA alone).  c8out: srt_enc_f16 (down2: planar
+    // input) stores its raw + act outputs in that form.  wpack16cs: up5's class-stacked fp16 weights [Cin/16][15][2][32][8] (srt_pack16_classstack_kernel).
+    int c8out;
+    const uint16_t* wpack16cs; size_t wpack16cs_stem;
     float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
     float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)
     size_t out_stem, out_tile;
@@ -107,6 +112,11 @@ int  srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, h
 int  srt_launch_enc_f16(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_dec_f16(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack16(const float* w, uint16_t* wp16, int Cin, int Cout, int CP, int dec, hipStream_t s);
+// C8-form fp16 kernels (srt_nn5.hip): return 1 when the layer is not covered
+int  srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_pack16_classstack(const float* w, uint16_t* wp, int Cin, int Cout, hipStream_t s);
+int  srt_launch_c8_to_float(const void* src, float* dst, int C, size_t hw, hipStream_t s);
 int  srt_launch_count_not_fp16(const float* w, size_t n, unsigned* d_count, hipStream_t s);   // weights the fp16 pack would round (SRT_PREC_F16X2 guard)
 int  srt_set_sigmoid_table(const float* tbl1026);
 void srt_fp16_expand(const uint16_t* d_in, float* d_out, size_t n, hipStream_t s);

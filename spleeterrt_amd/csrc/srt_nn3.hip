@@ -449,6 +449,28 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
         const int oy = ty0 + sy * SH + l31 / SW, ox = tx0 + sx * SW + l31 % SW, tile = tile0 + il;
         const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
         const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
+        if (A16 && p.c8out) {
+            // C8 stores (srt_nn5.hip): the lane's four consecutive channels (r & 3) of channel group m0/8 + (r >> 2) are one 8-byte piece; the two lane
+            // halves (g) and 32 neighbouring pixels make 512 contiguous bytes per store instruction
+            _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+            _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+            const size_t cb = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + ((size_t)(m0 / 8) * ohw + (pix_ok ? (size_t)oy * Wo + ox : 0)) * 8 + 4 * g;
+            if (pix_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h4 rv, av;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = acc[nr][4 * q + j] + bi[4 * q + j];
+                        rv[j] = (_Float16)v;
+                        av[j] = (_Float16)srt_enc_epilogue(v, sc[4 * q + j], sf[4 * q + j], actp);
+                    }
+                    *reinterpret_cast<h4*>(rawh + cb + (size_t)q * ohw * 8) = rv;
+                    if (twoOut) *reinterpret_cast<h4*>(acth + cb + (size_t)q * ohw * 8) = av;
+                }
+            }
+            continue;
+        }
         if (A16) {
             _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
             _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);

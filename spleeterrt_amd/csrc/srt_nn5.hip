@@ -1,0 +1,451 @@
+// srt_nn5.hip — the fp16-storage layers of large batches in "C8" form (round 6): down3..down6 (spleeter.c:96-100, im2col_dilated.c:10-33) and
+// up1..up5 (spleeter.c:73-78, im2col_dilated.c:34-65) on v_mfma_f32_32x32x16_f16, fed by LDS-DMA only.
+//
+// Why a second fp16 form.  The kernels of srt_nn3.hip read PLANAR half tensors ([C][H][W]): the B operand of the fp16 MFMA wants the 8 input channels of a
+// k-group contiguous per pixel, so every staged value goes global -> VGPR -> register transpose -> ds_write, 16 eight-byte loads and ~100 VALU operations per
+// thread and K chunk beside 25 MFMAs, one tile per workgroup, one chunk of prefetch.  At the 5-stem batch those layers sat under NEITHER roof (round-6 counters,
+// profiles/r06a_f16_pmc.json: down3 0.34 ms at 0.18 matrix-pipe busy and 0.46 wait; 10 us per workgroup for 0.8 us of MFMAs).  Here the activation tensors between
+// down2 and up5 are stored channel-interleaved by eight,
+//     C8:  element (c, y, x) of an instance at ((c / 8) * H * W + y * W + x) * 8 + c % 8          (16 B = the 8 channels of one k-group at one pixel)
+// which IS the B-fragment layout: a patch goes HBM -> LDS by buffer_load_dwordx4 ... lds (16 B per lane, out-of-image lanes land as zeros through the buffer range
+// check), no register staging, no transposes, and the MFMA epilogue writes 8-byte pieces that tile whole 64-B lines (the planar form wrote 2-byte pieces).
+// A workgroup is 8 waves, one 32-pixel sub-tile each, sharing one 32-row weight slab per 16-channel K chunk; it walks `tpw` consecutive (instance group, tile)
+// units of one (stem, M block) as ONE stream of K steps through an LDS ring (patch + slab per stage): the DMA of step s+1 (s+2 in the decoder) is in flight under
+// the MFMAs of step s across unit boundaries, and a unit's epilogue is issued right after the next step's DMA, in its shadow.  One barrier per step.
+// Tensors in C8: raw2..raw6, act2..act5, up1..up4 (srt_engine.hip: forward_range, `c8`); down1 / down2's input / up5's output / up6 stay planar, so
+// srt_down1_stream_kernel and srt_up6_stream_kernel are untouched: down2 (srt_enc_f16) only switches its epilogue, up5 runs here with planar stores.
+#include "srt_device.h"
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// s_waitcnt immediate for "at most n vector-memory operations outstanding" (gfx9 encoding, see srt_nn4.hip)
+constexpr int c8_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+constexpr unsigned C8_OOR = 0x80000000u;                       // >= num_records: the DMA lands zeros
+
+// All DMA from inline assembly (the compiler's own LDS-DMA bookkeeping would wait vmcnt(0) before every later LDS read, srt_nn4.hip)
+__device__ __forceinline__ void c8_dma_buffer(unsigned voff, i32x4 rs, unsigned soff, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void c8_dma_global(unsigned voff, const void* sbase, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ i32x4 c8_rsrc(const void* base, unsigned nrec)
+{
+    const size_t b = (size_t)base;
+    i32x4 rs;
+    rs.x = (int)(unsigned)(b & 0xffffffffu); rs.y = (int)(unsigned)((b >> 32) & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
+    return rs;
+}
+
+// ------------------------------------------------------------------------------------------- packing / unpacking
+// up5 (Cout = 16): the two x-parity classes of an output row share an input shift, so their 16 + 16 output channels fill one 32-row MFMA tile:
+// wp[((cg*15 + ky*3 + (dx+1))*2 + g)*32 + px*16 + co][q] = w[ci = cg*16 + g*8 + q][co][ky][kx],  kx = px + 1 - 2 dx (zero outside 0..4) - 15 MFMAs per
+// K chunk and sub-tile instead of 25 half-empty ones (the fp32 form of the same idea: srt_pack_classstack_kernel, srt_nn2.hip)
+__global__ void srt_pack16_classstack_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout)
+{
+    const int total = (Cin / 16) * 15 * 2 * 32 * 8;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int q = e % 8, row = (e / 8) % 32, g = (e / 256) % 2, t = (e / 512) % 15, cg = e / (512 * 15);
+        const int px = row / 16, co = row % 16, ky = t / 3, dx = t % 3 - 1, kx = px + 1 - 2 * dx, ci = cg * 16 + g * 8 + q;
+        wp[e] = (_Float16)((kx >= 0 && kx < 5 && co < Cout) ? w[((size_t)ci * Cout + co) * 25 + ky * 5 + kx] : 0.0f);
+    }
+}
+int srt_launch_pack16_classstack(const float* w, uint16_t* wp, int Cin, int Cout, hipStream_t s)
+{
+    SRT_LAUNCH(srt_pack16_classstack_kernel, dim3(64), dim3(256), 0, s, w, (_Float16*)wp, Cin, Cout);
+    return srt_launch_status();
+}
+// test taps (srtCopyTensor): one instance, C8 halves -> planar floats
+__global__ void srt_c8_to_float_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int C, size_t hw)
+{
+    const size_t total = (size_t)C * hw;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / hw); const size_t pix = e % hw;
+        dst[e] = (float)src[((size_t)(c / 8) * hw + pix) * 8 + c % 8];
+    }
+}
+int srt_launch_c8_to_float(const void* src, float* dst, int C, size_t hw, hipStream_t s)
+{
+    SRT_LAUNCH(srt_c8_to_float_kernel, dim3(1024), dim3(256), 0, s, (const _Float16*)src, dst, C, hw);
+    return srt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------- encoder, C8 in -> C8 out (raw + act)
+// Tile = TH x TW outputs of NI instances = 8 sub-tiles of 32 pixels (SW wide), one per wave; M block = 32 output channels.
+// LDS patch of a stage: [k-group 2][NI][PH = 2 TH + 3 rows][even columns PWH | odd columns PWH] pixel slots of 16 B: the stride-2 taps of 32 neighbouring
+// outputs read 32 neighbouring slots (conflict-free ds_read_b128), the split is done by the DMA's per-lane source addresses.
+template <int SW, int NSY, int NI>
+__global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int tpw)
+{
+    static_assert(NSY * NI == 8 && 32 % SW == 0, "one 32-pixel sub-tile per wave");
+    constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
+    constexpr int PH = 2 * TH + 3, PWH = TW + 3, ROWS = 2 * PWH;
+    constexpr int PLANE = NI * PH * ROWS;                      // 16-B slots per k-group plane
+    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + 7) / 8;
+    constexpr int PATCH_H = NPP * 512, WSLAB_H = 25 * 512, WPW = 4;   // halves; the slab = 25 pieces of 1 KiB (two (tap, k-group) rows of 32 x 16 B each)
+    constexpr int STAGE_H = PATCH_H + WSLAB_H;
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[2 * STAGE_H];
+    static_assert(sizeof(s_mem) <= 160 * 1024, "LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH, nsp = tilesX * tilesY;
+    const int groups = (p.ntiles + NI - 1) / NI, nunits = nsp * groups;
+    const int upw = (nunits + tpw - 1) / tpw, MBK = p.Cout / 32;
+    const int pos = srt_xcd_order(upw * MBK * p.nstems);
+    const int wsel = pos / upw, mblk = wsel % MBK, stem = wsel / MBK, m0 = mblk * 32;
+    const int unit0 = (pos % upw) * tpw, unit1 = min(unit0 + tpw, nunits);
+    const int nch = p.Cin / 16, nsteps = (unit1 - unit0) * nch;
+    if (nsteps <= 0) return;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)s_mem;
+
+    // ---- weight slab DMA: wave w moves pieces w, w+8, w+16, min(w+24, 24)
+    const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
+    const size_t cgStride = (size_t)50 * p.CP * 8;             // halves per 16-channel chunk
+    unsigned wvoff[WPW], wm0[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int piece = min(wave + 8 * i, 24);
+        wvoff[i] = (unsigned)(((2 * piece + g) * p.CP + l31) * 16);
+        wm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PATCH_H * 2 + piece * 1024));
+    }
+    // ---- patch DMA: slot e = ((gg * NI + il) * PH + r) * ROWS + slot of the stage <- k-group gg of the chunk, instance tile0 + il, input row 2 ty0 - 1 + r,
+    // input column 2 tx0 - 4 + 2 idx + par (slot = par * PWH + idx)
+    unsigned pvoff[PPW], pm0[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(wave + 8 * i, NPP - 1) * 1024));
+    const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)2 * NI * p.srcA_tile);
+    const _Float16* pa = nullptr;                              // wave-uniform: plane 0 of the DMA unit's first instance
+    auto set_dma_unit = [&](int unit) {
+        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int e = min(wave + 8 * i, NPP - 1) * 64 + lane;
+            const int gg = e / PLANE, rem = e % PLANE, slot = rem % ROWS, r = (rem / ROWS) % PH, il = rem / (ROWS * PH);
+            const int par = slot >= PWH ? 1 : 0, idx = slot - par * PWH;
+            const int gy = 2 * ty0 - 1 + r, gx = 2 * tx0 - 4 + 2 * idx + par;
+            const bool ok = e < PITEMS && tile0 + il < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            pvoff[i] = ok ? (unsigned)(2 * (size_t)il * p.srcA_tile + 16 * ((size_t)gg * hw + (size_t)gy * p.W + gx)) : C8_OOR;
+        }
+        pa = reinterpret_cast<const _Float16*>(p.srcA) + stem * p.srcA_stem + tile0 * p.srcA_tile;
+    };
+    const unsigned chunk_bytes = (unsigned)(32 * hw);          // two C8 planes
+    auto issue_dma = [&](int ch, int stage) {
+        const unsigned sb = (unsigned)stage * (unsigned)(STAGE_H * 2);
+        const i32x4 rs = c8_rsrc(pa, nrec);
+        const _Float16* ws = wp + (size_t)ch * cgStride;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, (unsigned)ch * chunk_bytes, pm0[i] + sb);
+    };
+
+    // ---- this wave's sub-tile
+    const int il_w = wave / NSY, sy = wave % NSY, oy_l = sy * SH + l31 / SW, ox_l = l31 % SW;
+    const int boff = (g * PLANE + (il_w * PH + 2 * oy_l) * ROWS + ox_l) * 8;
+    const int aoff = (g * 32 + l31) * 8;
+    const size_t ohw = (size_t)Ho * Wo;
+    const bool twoOut = p.outAct != nullptr && p.bnScale != nullptr;
+    float bi[16], sc[16], sf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t ci = stem * p.coeff_stem + m0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        bi[r] = p.bias[ci]; sc[r] = twoOut ? p.bnScale[ci] : 0.0f; sf[r] = twoOut ? p.bnShift[ci] : 0.0f;
+    }
+    _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+    _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+    size_t obase = 0; bool pix_ok = false;
+    auto set_out_unit = [&](int unit) {
+        const int sp = unit % nsp, tile = (unit / nsp) * NI + il_w, oy = (sp / tilesX) * TH + oy_l, ox = (sp % tilesX) * TW + ox_l;
+        pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
+        obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + ((size_t)(m0 / 8) * ohw + (pix_ok ? (size_t)oy * Wo + ox : 0)) * 8 + 4 * g;
+    };
+    f32x16 acc;
+    auto epilogue = [&]() {
+        if (!pix_ok) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h4 rv, av;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[4 * q + j] + bi[4 * q + j];                                  // conv + bias: the skip tensor
+                rv[j] = (_Float16)v;
+                av[j] = (_Float16)srt_enc_epilogue(v, sc[4 * q + j], sf[4 * q + j], actp);
+            }
+            *reinterpret_cast<h4*>(rawh + obase + (size_t)q * ohw * 8) = rv;
+            if (twoOut) *reinterpret_cast<h4*>(acth + obase + (size_t)q * ohw * 8) = av;
+        }
+    };
+
+    int du = unit0, dch = 0, cu = unit0, ch = 0;
+    set_dma_unit(unit0);
+    issue_dma(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));               // this wave's pieces of step s have landed (and its older stores)
+        __syncthreads();                                       // everybody's have; everybody is past step s-1 (its stage is free)
+        if (s + 1 < nsteps) {
+            if (++dch == nch) { dch = 0; set_dma_unit(++du); }
+            issue_dma(dch, (s + 1) & 1);
+        }
+        if (ch == 0) {
+            if (s > 0) epilogue();                             // the previous unit's stores go out in the shadow of the DMA just issued
+            set_out_unit(cu);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
+        const _Float16* spatch = s_mem + (s & 1) * STAGE_H;
+        const _Float16* sw = spatch + PATCH_H;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int ky = tap / 5, kx = tap % 5;
+            const int koff = (ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)) * 8;
+            const h8 a = *reinterpret_cast<const h8*>(sw + tap * 512 + aoff);
+            const h8 b = *reinterpret_cast<const h8*>(spatch + boff + koff);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+        if (++ch == nch) { ch = 0; ++cu; }
+    }
+    epilogue();
+}
+
+// ------------------------------------------------------------------------------------------- decoder, C8 in -> C8 out (or planar out: up5)
+// Transposed 5x5 stride-2 convolution as four parity classes of the output (srt_nn3.hip: srt_dec_f16); one 32-pixel INPUT sub-tile per wave, all four
+// classes accumulated from one B fragment per input shift.  CS (up5, Cout = 16): class-stacked weights - 32 rows = 2 x-classes x 16 channels, 15 (ky, dx)
+// products per chunk, two accumulators (one per row class) - and planar fp16 stores (srt_up6_stream_kernel reads planar halves).
+template <int SW, int NSY, int NI, int ST, bool CS>
+__global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int tpw)
+{
+    static_assert(NSY * NI == 8 && 32 % SW == 0 && ST >= 2 && ST <= 4, "one 32-pixel sub-tile per wave");
+    constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
+    constexpr int PH = TH + 2, PC = TW + 2;
+    constexpr int PLANE = NI * PH * PC;
+    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + 7) / 8;
+    constexpr int NT = CS ? 15 : 25, WPW = (NT + 7) / 8;       // NT pieces of 1 KiB: the two k-group rows of one tap (or (ky, dx) pair)
+    constexpr int PATCH_H = NPP * 512, WSLAB_H = NT * 512, STAGE_H = PATCH_H + WSLAB_H;
+    constexpr int DPW = PPW + WPW;                             // DMA instructions per wave and step
+    constexpr int NACC = CS ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[ST * STAGE_H];
+    static_assert(sizeof(s_mem) <= 160 * 1024, "LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH, nsp = tilesX * tilesY;
+    const int groups = (p.ntiles + NI - 1) / NI, nunits = nsp * groups;
+    const int upw = (nunits + tpw - 1) / tpw, MBK = CS ? 1 : p.Cout / 32;
+    const int pos = srt_xcd_order(upw * MBK * p.nstems);
+    const int wsel = pos / upw, mblk = wsel % MBK, stem = wsel / MBK, m0 = mblk * 32;
+    const int unit0 = (pos % upw) * tpw, unit1 = min(unit0 + tpw, nunits);
+    const int nch = p.Cin / 16, nsteps = (unit1 - unit0) * nch;
+    if (nsteps <= 0) return;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)s_mem;
+
+    const _Float16* wp = CS ? (const _Float16*)(p.wpack16cs + stem * p.wpack16cs_stem)
+                            : (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
+    const int CPW = CS ? 32 : p.CP;
+    const size_t cgStride = (size_t)(2 * NT) * CPW * 8;
+    unsigned wvoff[WPW], wm0[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int piece = min(wave + 8 * i, NT - 1);
+        wvoff[i] = (unsigned)(((2 * piece + g) * CPW + l31) * 16);
+        wm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PATCH_H * 2 + piece * 1024));
+    }
+    // patch slot e = ((gg * NI + il) * PH + r) * PC + col <- k-group gg of the chunk, instance tile0 + il, input row ty0 - 1 + r, column tx0 - 1 + col
+    unsigned pvoff[PPW], pm0[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(wave + 8 * i, NPP - 1) * 1024));
+    const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)2 * NI * p.srcA_tile);     // srcA_tile == srcB_tile (launcher)
+    const _Float16* pa = nullptr; const _Float16* pb = nullptr;
+    auto set_dma_unit = [&](int unit) {
+        const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int e = min(wave + 8 * i, NPP - 1) * 64 + lane;
+            const int gg = e / PLANE, rem = e % PLANE, col = rem % PC, r = (rem / PC) % PH, il = rem / (PC * PH);
+            const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
+            const bool ok = e < PITEMS && tile0 + il < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            pvoff[i] = ok ? (unsigned)(2 * (size_t)il * p.srcA_tile + 16 * ((size_t)gg * hw + (size_t)gy * p.W + gx)) : C8_OOR;
+        }
+        pa = reinterpret_cast<const _Float16*>(p.srcA) + stem * p.srcA_stem + tile0 * p.srcA_tile;
+        pb = reinterpret_cast<const _Float16*>(p.srcB) + stem * p.srcB_stem + tile0 * p.srcB_tile;
+    };
+    const int chA = p.CA / 16;                                 // chunks [0, chA) read the skip tensor, the rest the previous decoder output
+    const unsigned chunk_bytes = (unsigned)(32 * hw);
+    auto issue_dma = [&](int ch, int stage) {
+        const unsigned sb = (unsigned)stage * (unsigned)(STAGE_H * 2);
+        const bool fromA = ch < chA;
+        const i32x4 rs = c8_rsrc(fromA ? pa : pb, nrec);
+        const unsigned soff = (unsigned)(fromA ? ch : ch - chA) * chunk_bytes;
+        const _Float16* ws = wp + (size_t)ch * cgStride;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, soff, pm0[i] + sb);
+    };
+
+    const int il_w = wave / NSY, sy = wave % NSY, a_l = sy * SH + l31 / SW, b_l = l31 % SW;
+    const int boff = (g * PLANE + (il_w * PH + a_l + 1) * PC + b_l + 1) * 8;
+    const int aoff = (g * 32 + l31) * 8;
+    const int Wo = p.W << 1;
+    const size_t ohw = (size_t)(p.H << 1) * Wo;
+    float bi[16], sc[16], sf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        const size_t ci = stem * p.coeff_stem + (CS ? row % 16 : m0 + row);
+        bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+    }
+    _Float16* outh = reinterpret_cast<_Float16*>(p.outAct);
+    size_t obase = 0; bool pix_ok = false;
+    auto set_out_unit = [&](int unit) {
+        const int sp = unit % nsp, tile = (unit / nsp) * NI + il_w, a = (sp / tilesX) * TH + a_l, b = (sp % tilesX) * TW + b_l;
+        pix_ok = tile < p.ntiles && a < p.H && b < p.W;
+        const size_t pix = pix_ok ? (size_t)(2 * a) * Wo + 2 * b : 0;
+        obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (CS ? pix : ((size_t)(m0 / 8) * ohw + pix) * 8 + 4 * g);
+    };
+    f32x16 acc[NACC];
+    auto epilogue = [&]() {
+        if (!pix_ok) return;
+        if constexpr (CS) {
+            // rows of the MFMA tile: m = 8 q + 4 g + j = px * 16 + co  ->  px = q >> 1, co = 8 (q & 1) + 4 g + j
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r0 = 4 * qq + j, r1 = 4 * (qq + 2) + j, co = 8 * qq + 4 * g + j;
+                        const h2 hv = { (_Float16)srt_dec_epilogue(acc[py][r0], bi[r0], sc[r0], sf[r0], actp),
+                                        (_Float16)srt_dec_epilogue(acc[py][r1], bi[r1], sc[r1], sf[r1], actp) };
+                        *reinterpret_cast<h2*>(outh + obase + (size_t)co * ohw + (size_t)py * Wo) = hv;
+                    }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        h4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (_Float16)srt_dec_epilogue(acc[py * 2 + px][4 * q + j], bi[4 * q + j], sc[4 * q + j], sf[4 * q + j], actp);
+                        *reinterpret_cast<h4*>(outh + obase + ((size_t)q * ohw + (size_t)py * Wo + px) * 8) = v;
+                    }
+        }
+    };
+
+    int du = unit0, dch = 0, cu = unit0, ch = 0, issued = 0;
+    set_dma_unit(unit0);
+    auto issue_next = [&]() {                                  // the step after the last one issued (always exactly DPW instructions: past the end, step 0 of the last unit again - harmless, its stage is free)
+        issue_dma(dch, issued % ST);
+        ++issued;
+        if (issued < nsteps && ++dch == nch) { dch = 0; set_dma_unit(++du); }
+    };
+    for (int i = 0; i < ST - 1; ++i) issue_next();
+    for (int s = 0; s < nsteps; ++s) {
+        // everything older than this wave's pieces of the ST-2 newest steps has landed: step s (stores only make the wait longer: loads retire in order)
+        __builtin_amdgcn_s_waitcnt(c8_vmcnt((ST - 2) * DPW));
+        __syncthreads();
+        issue_next();                                          // step s + ST - 1 into the stage step s - 1 just left
+        if (ch == 0) {
+            if (s > 0) epilogue();
+            set_out_unit(cu);
+#pragma unroll
+            for (int c = 0; c < NACC; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        }
+        const _Float16* spatch = s_mem + (s % ST) * STAGE_H;
+        const _Float16* sw = spatch + PATCH_H;
+#pragma unroll
+        for (int sh = 0; sh < 9; ++sh) {                       // shift-major: one B fragment per input shift
+            const int dy = sh / 3 - 1, dx = sh % 3 - 1;
+            const h8 b = *reinterpret_cast<const h8*>(spatch + boff + (dy * PC + dx) * 8);
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int py = (ky + 1) & 1;
+                if ((py + 1 - ky) / 2 != dy) continue;
+                if constexpr (CS) {
+                    const h8 a = *reinterpret_cast<const h8*>(sw + (ky * 3 + dx + 1) * 512 + aoff);
+                    acc[py] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[py], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int px = (kx + 1) & 1;
+                        if ((px + 1 - kx) / 2 != dx) continue;
+                        const h8 a = *reinterpret_cast<const h8*>(sw + (ky * 5 + kx) * 512 + aoff);
+                        acc[py * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[py * 2 + px], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (++ch == nch) { ch = 0; ++cu; }
+    }
+    __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));                   // the tail's harmless extra DMA must not outlive the workgroup's LDS
+    epilogue();
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+static int c8_target_wgs()
+{
+    static int v = -1;
+    if (v < 0) { const char* t = getenv("SPLEETERRT_C8_WGS"); v = t ? atoi(t) : 0; if (v <= 0) v = 1024; }
+    return v;
+}
+// units per workgroup: about c8_target_wgs() workgroups per launch (4 rounds of the 256 CUs), never across a (stem, M block) boundary
+static int c8_tpw(int nunits, int pairs)
+{
+    const int upw = c8_target_wgs() / pairs > 0 ? c8_target_wgs() / pairs : 1;
+    const int tpw = (nunits + upw - 1) / upw;
+    return tpw < 1 ? 1 : tpw;
+}
+
+int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s)
+{
+    if (!p.wpack16 || p.Cin % 16 || p.Cout % 32 || !p.in16 || !p.out16 || p.nsplit == 2 || p.inScale) return 1;
+    const int Ho = p.H / 2, Wo = p.W / 2, pairs = (p.Cout / 32) * p.nstems;
+    if (Wo > 16) {
+        constexpr int TH = 8, TW = 32, NI = 1;
+        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        SRT_LAUNCH((srt_enc_c8<32, 8, 1>), dim3((unsigned)(((nunits + tpw - 1) / tpw) * pairs)), dim3(512), 0, s, p, tpw);
+    } else {
+        constexpr int TH = 4, TW = 16, NI = 4;
+        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        SRT_LAUNCH((srt_enc_c8<16, 2, 4>), dim3((unsigned)(((nunits + tpw - 1) / tpw) * pairs)), dim3(512), 0, s, p, tpw);
+    }
+    return srt_launch_status();
+}
+
+int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
+{
+    const bool cs = p.Cout == 16;
+    if (p.Cin % 16 || p.CA % 16 || !p.in16 || !p.out16 || p.nsplit == 2 || (cs ? !p.wpack16cs : (!p.wpack16 || p.Cout % 32 != 0))) return 1;
+    if (p.CA < p.Cin && p.srcA_tile != p.srcB_tile) return -1;
+    const int pairs = (cs ? 1 : p.Cout / 32) * p.nstems;
+    if (p.W > 16) {
+        constexpr int TH = 8, TW = 32, NI = 1;
+        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
+        if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true>), grid, dim3(512), 0, s, p, tpw);
+        else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false>), grid, dim3(512), 0, s, p, tpw);
+    } else {
+        constexpr int TH = 4, TW = 16, NI = 4;
+        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
+        if (cs) SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true>), grid, dim3(512), 0, s, p, tpw);
+        else SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false>), grid, dim3(512), 0, s, p, tpw);
+    }
+    return srt_launch_status();
+}

@@ -223,6 +223,54 @@ def test_up6_streamed_form_fp16_storage(oracle, coeffs):
     eng.close()
 
 
+@pytest.mark.parametrize("T,F,ntiles,modes", [(64, 512, 9, (1, 0)), (128, 1024, 5, (1, 0, 1, 1)), (64, 256, 17, (0,)), (192, 768, 6, (1, 1, 0))])
+def test_fp16_c8_layers(oracle, coeffs, T, F, ntiles, modes):
+    """fp16 storage, launches above 16 instances (round 6, csrc/srt_nn5.hip): the tensors between down2 and up5 are channel-interleaved by eight and down3..down6 /
+    up1..up5 run on the DMA-fed kernels.  Every tensor of sampled instances (first, middle, last tile: the last one sits in a partly empty instance group of the deep
+    layers) against (a) the SAME tile evaluated alone, which takes the planar kernels of srt_nn3.hip (same products, same order: fp16 rounding noise at most), and
+    (b) the fp32 CPU oracle at the fp16 tolerance class of BASELINE configs[4] (masks <= 2e-2).  Geometries: F = 256 (one-pixel-high deep layers, everything a
+    partial tile), T = 192 / F = 768 (tile counts that are not powers of two), the bench's 1024 bins."""
+    import torch
+    import spleeterrt_amd as srt
+    S = len(modes)
+    assert S * ntiles > 16
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, precision=srt.PREC_F16)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=606)
+    xd = torch.from_numpy(x).cuda()
+    masks = eng.forward(xd).cpu().numpy()
+    assert np.isfinite(masks).all()
+    names = ["conv%d" % i for i in range(1, 7)] + ["act%d" % i for i in range(1, 6)] + ["up%d" % i for i in range(1, 7)]
+    sample = [(s, t) for s in sorted({0, S - 1}) for t in sorted({0, ntiles // 2, ntiles - 1})]
+    big = {(s, t): {n: eng.tensor(n, s, t) for n in names} for (s, t) in sample}
+    ks = _layer_kernels(eng, xd)
+    for n in ("down3", "down4", "down5", "down6"):
+        assert ks[n].startswith("srt_enc_c8<"), (n, ks[n])
+    for n in ("up1", "up2", "up3", "up4", "up5"):
+        assert ks[n].startswith("srt_dec_c8<"), (n, ks[n])
+    worst = 0.0
+    for (s, t) in sample:
+        ref = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST)
+        d = float(np.abs(masks[s, t] - ref).max())
+        assert d <= 2e-2, (s, t, d)
+    for t in sorted({t for (_, t) in sample}):
+        one = torch.from_numpy(x[t:t + 1]).cuda()
+        m1 = eng.forward(one).cpu().numpy()
+        k1 = _layer_kernels(eng, one)
+        assert k1["down3"].startswith("srt_enc_f16<") and k1["up2"].startswith("srt_dec_f16<"), k1
+        for s in sorted({s for (s, _) in sample}):
+            for n in names:
+                a, b = big[(s, t)][n], eng.tensor(n, s, 0)
+                err = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+                worst = max(worst, err)
+                assert err <= 2e-3, "%s stem %d tile %d: C8 batch vs planar single tile, max abs / peak %g at %r" % (
+                    n, s, t, err, np.unravel_index(int(np.abs(a - b).argmax()), a.shape))
+            assert float(np.abs(masks[s, t] - m1[s, 0]).max()) <= 2e-3
+    print("fp16 C8 %dx%d x%d: worst tap difference to the planar path %.3g of the tensor peak" % (T, F, ntiles, worst))
+    eng.close()
+
+
 def test_forward_lut_variant(oracle, coeffs):
     import torch
     import spleeterrt_amd as srt
