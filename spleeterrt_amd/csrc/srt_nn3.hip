@@ -73,6 +73,16 @@ __device__ __forceinline__ void srt_dma_slab16(const _Float16* wp, int CP, _Floa
         }
     }
 }
+// lanes l and l + 32 trade halves: a = this lane's 8 bytes of slot A, b = of slot B; returns all 16 bytes of slot A (lanes 0-31) / slot B (lanes 32-63); see srt_nn5.hip
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 srt_c8_pair16(h4 a, h4 b)
+{
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+    return (u32x4){ r0[0], r1[0], r0[1], r1[1] };
+}
 __device__ __forceinline__ void srt_split(float x, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)x;
@@ -450,23 +460,29 @@ __global__ void __launch_bounds__(256, 2) srt_enc_f16(const SrtConvParams p)
         const bool pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
         const size_t obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (pix_ok ? (size_t)oy * Wo + ox : 0);
         if (A16 && p.c8out) {
-            // C8 stores (srt_nn5.hip): the lane's four consecutive channels (r & 3) of channel group m0/8 + (r >> 2) are one 8-byte piece; the two lane
-            // halves (g) and 32 neighbouring pixels make 512 contiguous bytes per store instruction
+            // C8 stores (srt_nn5.hip): the lane's four consecutive channels (r & 3) of channel group m0/8 + (r >> 2) are 8 bytes of a 16-byte pixel slot, lane + 32
+            // holds the other 8: one v_permlane32_swap per dword gives every lane a whole slot (low lanes the even group of a pair, high lanes the odd one) and
+            // the epilogue 16-byte stores, 1 KiB of whole lines per wave instruction
             _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
             _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
-            const size_t cb = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + ((size_t)(m0 / 8) * ohw + (pix_ok ? (size_t)oy * Wo + ox : 0)) * 8 + 4 * g;
-            if (pix_ok) {
+            const size_t cb = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + ((size_t)(m0 / 8 + g) * ohw + (pix_ok ? (size_t)oy * Wo + ox : 0)) * 8;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    h4 rv, av;
+            for (int k = 0; k < 2; ++k) {
+                h4 rv[2], av[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = acc[nr][4 * q + j] + bi[4 * q + j];
-                        rv[j] = (_Float16)v;
-                        av[j] = (_Float16)srt_enc_epilogue(v, sc[4 * q + j], sf[4 * q + j], actp);
+                        const int r = 4 * (2 * k + qq) + j;
+                        const float v = acc[nr][r] + bi[r];
+                        rv[qq][j] = (_Float16)v;
+                        av[qq][j] = (_Float16)srt_enc_epilogue(v, sc[r], sf[r], actp);
                     }
-                    *reinterpret_cast<h4*>(rawh + cb + (size_t)q * ohw * 8) = rv;
-                    if (twoOut) *reinterpret_cast<h4*>(acth + cb + (size_t)q * ohw * 8) = av;
+                const u32x4 r16 = srt_c8_pair16(rv[0], rv[1]);
+                if (pix_ok) *reinterpret_cast<u32x4*>(rawh + cb + (size_t)(2 * k) * ohw * 8) = r16;
+                if (twoOut) {
+                    const u32x4 a16 = srt_c8_pair16(av[0], av[1]);
+                    if (pix_ok) *reinterpret_cast<u32x4*>(acth + cb + (size_t)(2 * k) * ohw * 8) = a16;
                 }
             }
             continue;

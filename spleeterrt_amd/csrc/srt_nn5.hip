@@ -40,8 +40,61 @@ __device__ __forceinline__ i32x4 c8_rsrc(const void* base, unsigned nrec)
 {
     const size_t b = (size_t)base;
     i32x4 rs;
-    rs.x = (int)(unsigned)(b & 0xffffffffu); rs.y = (int)(unsigned)((b >> 32) & 0xffffu); rs.z = (int)nrec; rs.w = 0x00020000;
+    // (readfirstlane: the words are wave-uniform by construction; inside the loader-wave branch the compiler no longer proves it and would hand the asm VGPRs)
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffu)); rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)nrec); rs.w = 0x00020000;
     return rs;
+}
+
+// ------------------------------------------------------------------------------------------- epilogue arithmetic, two values per instruction
+// The generic per-value forms (srt_device.h: srt_enc_epilogue / srt_dec_epilogue through srt_act_apply) are ~15 VALU instructions + one v_exp_f32 per value:
+// with the 16x faster fp16 MFMA that was 30-45 % of these kernels (ablation, round 6).  Here a PAIR of values goes through v_pk_add/mul_f32 (the compiler forms
+// them from the 2-vector arithmetic below; max / min / exp stay scalar), with the activation kind a wave-uniform branch.  Same operations in the same order as
+// the generic forms (contraction off), so the values are the same up to the sign of a zero.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define F2(a, b) (f2){ (a), (b) }
+#pragma clang fp contract(off)
+__device__ __forceinline__ f2 c8_act_pair(f2 x, const SrtAct& a)
+{
+    if (a.ue != 0.0f) {
+        if (srt_act_is_plain_elu(a)) {                         // max(x, 0) + (exp(min(x, 0)) - 1)
+            const f2 m = { fminf(x.x, 0.0f), fminf(x.y, 0.0f) };
+            const f2 e = { __expf(m.x), __expf(m.y) };
+            const f2 p = { fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f) };
+            return p + (e - 1.0f);
+        }
+        return F2(srt_act_apply(x.x, a), srt_act_apply(x.y, a));
+    }
+    const f2 l = x * a.lin;                                    // LeakyReLU / ReLU: max(x, lin x)
+    return F2(fmaxf(x.x, l.x), fmaxf(x.y, l.y));
+}
+__device__ __forceinline__ f2 c8_dec_pair(f2 acc, f2 bias, f2 scale, f2 shift, const SrtAct& a)
+{
+    const f2 v = c8_act_pair(acc + bias, a);                   // spleeter.c:244-245: activation BEFORE BN
+    return scale * v + shift;
+}
+__device__ __forceinline__ void c8_enc_pair(f2 acc, f2 bias, f2 scale, f2 shift, const SrtAct& a, f2& raw, f2& act)
+{
+    raw = acc + bias;                                          // conv + bias: the skip tensor
+    act = c8_act_pair(scale * raw + shift, a);                 // spleeter.c:188
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------- 16-byte stores from the MFMA accumulator layout
+// A lane of the 32x32 MFMA result holds FOUR consecutive channels (rows 8 q + 4 g + 0..3) of its pixel: 8 bytes of a C8 pixel slot, the other 8 in lane + 32.
+// Stored as they are, an epilogue is 8-byte stores - and the store path, not the arithmetic, was what the epilogue cost (round 6: halving the VALU count moved
+// nothing; MI355X_MICROARCH.md: store tails are issue-bound, dwordx4 halves them).  One v_permlane32_swap per dword trades halves between lanes l and l + 32 so
+// that each lane ends up with ALL eight channels of ONE slot (the low lane: slot A, the high lane: slot B): one 16-byte store per lane where there were two 8-byte
+// ones, a wave writing 1 KiB of whole lines per instruction.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// a = this lane's channels of slot A, b = its channels of slot B.  Returns the 16 bytes of the slot the lane stores: slot A for lanes 0-31, slot B for lanes 32-63.
+__device__ __forceinline__ u32x4 c8_pair16(h4 a, h4 b)
+{
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);     // r[0]: low lanes keep a, high lanes get the low partner's b; r[1]: low lanes get the high partner's a, high lanes keep b
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+    return (u32x4){ r0[0], r1[0], r0[1], r1[1] };
 }
 
 // ------------------------------------------------------------------------------------------- packing / unpacking
@@ -78,24 +131,32 @@ int srt_launch_c8_to_float(const void* src, float* dst, int C, size_t hw, hipStr
 }
 
 // ------------------------------------------------------------------------------------------- encoder, C8 in -> C8 out (raw + act)
-// Tile = TH x TW outputs of NI instances = 8 sub-tiles of 32 pixels (SW wide), one per wave; M block = 32 output channels.
+// Tile = TH x TW outputs of NI instances = 8 sub-tiles of 32 pixels (SW wide); M block = 32 output channels.
 // LDS patch of a stage: [k-group 2][NI][PH = 2 TH + 3 rows][even columns PWH | odd columns PWH] pixel slots of 16 B: the stride-2 taps of 32 neighbouring
 // outputs read 32 neighbouring slots (conflict-free ds_read_b128), the split is done by the DMA's per-lane source addresses.
-template <int SW, int NSY, int NI>
+// LW (both kernels): 0 (shipped) - every one of the 8 waves moves its share of the DMA pieces AND computes one sub-tile.  1 (tuning library) - waves 0-3 compute
+// two sub-tiles each (one A fragment per two MFMAs), waves 4-7 only issue DMA, so that the 60-190 cycles an LDS-DMA instruction holds its wave
+// (MI355X_MICROARCH.md) are not taken from a computing wave.  Measured slower (see the dispatch section).
+// ABL (SRT_TUNING builds only; wrong results): timing ablations - 1 no patch DMA after the ring is primed, 2 no weight DMA, 4 no MFMAs (and no LDS reads), 8 no
+// epilogue, 16 MFMAs on constant operands (no LDS reads), 32 no barrier / no DMA wait
+template <int SW, int NSY, int NI, int LW, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int tpw)
 {
-    static_assert(NSY * NI == 8 && 32 % SW == 0, "one 32-pixel sub-tile per wave");
+    static_assert(NSY * NI == 8 && 32 % SW == 0, "eight 32-pixel sub-tiles");
     constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
+    constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : 1;            // waves that issue DMA; sub-tiles per computing wave
     constexpr int PH = 2 * TH + 3, PWH = TW + 3, ROWS = 2 * PWH;
     constexpr int PLANE = NI * PH * ROWS;                      // 16-B slots per k-group plane
-    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + 7) / 8;
-    constexpr int PATCH_H = NPP * 512, WSLAB_H = 25 * 512, WPW = 4;   // halves; the slab = 25 pieces of 1 KiB (two (tap, k-group) rows of 32 x 16 B each)
+    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + NLW - 1) / NLW;
+    constexpr int PATCH_H = NPP * 512, WSLAB_H = 25 * 512, WPW = (25 + NLW - 1) / NLW;   // halves; the slab = 25 pieces of 1 KiB (two (tap, k-group) rows of 32 x 16 B each)
     constexpr int STAGE_H = PATCH_H + WSLAB_H;
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[2 * STAGE_H];
     static_assert(sizeof(s_mem) <= 160 * 1024, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = !LW || wave >= 4, worker = !LW || wave < 4;
+    const int lw = LW ? (wave & 3) : wave;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH, nsp = tilesX * tilesY;
     const int groups = (p.ntiles + NI - 1) / NI, nunits = nsp * groups;
@@ -109,13 +170,13 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
     const size_t hw = (size_t)p.H * p.W;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)s_mem;
 
-    // ---- weight slab DMA: wave w moves pieces w, w+8, w+16, min(w+24, 24)
+    // ---- weight slab DMA: loader lw moves pieces lw, lw + NLW, ... (past the last piece: the last piece again - same bytes, no branch)
     const _Float16* wp = (const _Float16*)(p.wpack16 + stem * p.wpack16_stem) + (size_t)m0 * 8;
     const size_t cgStride = (size_t)50 * p.CP * 8;             // halves per 16-channel chunk
     unsigned wvoff[WPW], wm0[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int piece = min(wave + 8 * i, 24);
+        const int piece = min(lw + NLW * i, 24);
         wvoff[i] = (unsigned)(((2 * piece + g) * p.CP + l31) * 16);
         wm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PATCH_H * 2 + piece * 1024));
     }
@@ -123,14 +184,14 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
     // input column 2 tx0 - 4 + 2 idx + par (slot = par * PWH + idx)
     unsigned pvoff[PPW], pm0[PPW];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(wave + 8 * i, NPP - 1) * 1024));
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(lw + NLW * i, NPP - 1) * 1024));
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)2 * NI * p.srcA_tile);
     const _Float16* pa = nullptr;                              // wave-uniform: plane 0 of the DMA unit's first instance
     auto set_dma_unit = [&](int unit) {
         const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int e = min(wave + 8 * i, NPP - 1) * 64 + lane;
+            const int e = min(lw + NLW * i, NPP - 1) * 64 + lane;
             const int gg = e / PLANE, rem = e % PLANE, slot = rem % ROWS, r = (rem / ROWS) % PH, il = rem / (ROWS * PH);
             const int par = slot >= PWH ? 1 : 0, idx = slot - par * PWH;
             const int gy = 2 * ty0 - 1 + r, gx = 2 * tx0 - 4 + 2 * idx + par;
@@ -140,19 +201,29 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
         pa = reinterpret_cast<const _Float16*>(p.srcA) + stem * p.srcA_stem + tile0 * p.srcA_tile;
     };
     const unsigned chunk_bytes = (unsigned)(32 * hw);          // two C8 planes
-    auto issue_dma = [&](int ch, int stage) {
+    auto issue_dma = [&](int ch, int stage, bool primed) {
         const unsigned sb = (unsigned)stage * (unsigned)(STAGE_H * 2);
         const i32x4 rs = c8_rsrc(pa, nrec);
         const _Float16* ws = wp + (size_t)ch * cgStride;
+        if (!((ABL & 2) && primed)) {
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+            for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+        }
+        if (!((ABL & 1) && primed)) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, (unsigned)ch * chunk_bytes, pm0[i] + sb);
+            for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, (unsigned)ch * chunk_bytes, pm0[i] + sb);
+        }
     };
 
-    // ---- this wave's sub-tile
-    const int il_w = wave / NSY, sy = wave % NSY, oy_l = sy * SH + l31 / SW, ox_l = l31 % SW;
-    const int boff = (g * PLANE + (il_w * PH + 2 * oy_l) * ROWS + ox_l) * 8;
+    // ---- this wave's sub-tiles: NR * (wave & (8 / NR - 1)) + n
+    int boff[NR], il_w[NR], oy_l[NR];
+    const int ox_l = l31 % SW;
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int st = NR * (LW ? (wave & 3) : wave) + n;
+        il_w[n] = st / NSY; oy_l[n] = (st % NSY) * SH + l31 / SW;
+        boff[n] = (g * PLANE + (il_w[n] * PH + 2 * oy_l[n]) * ROWS + ox_l) * 8;
+    }
     const int aoff = (g * 32 + l31) * 8;
     const size_t ohw = (size_t)Ho * Wo;
     const bool twoOut = p.outAct != nullptr && p.bnScale != nullptr;
@@ -164,81 +235,128 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
     }
     _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
     _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
-    size_t obase = 0; bool pix_ok = false;
+    size_t obase[NR]; bool pix_ok[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) { obase[n] = 0; pix_ok[n] = false; }
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = (unit / nsp) * NI + il_w, oy = (sp / tilesX) * TH + oy_l, ox = (sp % tilesX) * TW + ox_l;
-        pix_ok = tile < p.ntiles && oy < Ho && ox < Wo;
-        obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + ((size_t)(m0 / 8) * ohw + (pix_ok ? (size_t)oy * Wo + ox : 0)) * 8 + 4 * g;
-    };
-    f32x16 acc;
-    auto epilogue = [&]() {
-        if (!pix_ok) return;
+        const int sp = unit % nsp;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h4 rv, av;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = acc[4 * q + j] + bi[4 * q + j];                                  // conv + bias: the skip tensor
-                rv[j] = (_Float16)v;
-                av[j] = (_Float16)srt_enc_epilogue(v, sc[4 * q + j], sf[4 * q + j], actp);
-            }
-            *reinterpret_cast<h4*>(rawh + obase + (size_t)q * ohw * 8) = rv;
-            if (twoOut) *reinterpret_cast<h4*>(acth + obase + (size_t)q * ohw * 8) = av;
+        for (int n = 0; n < NR; ++n) {
+            const int tile = (unit / nsp) * NI + il_w[n], oy = (sp / tilesX) * TH + oy_l[n], ox = (sp % tilesX) * TW + ox_l;
+            pix_ok[n] = tile < p.ntiles && oy < Ho && ox < Wo;
+            // the lane stores channel group m0/8 + 2 k + g of its pixel (c8_pair16: low lanes the even group of a pair, high lanes the odd one)
+            obase[n] = stem * p.out_stem + (pix_ok[n] ? tile : 0) * p.out_tile + ((size_t)(m0 / 8 + g) * ohw + (pix_ok[n] ? (size_t)oy * Wo + ox : 0)) * 8;
         }
+    };
+    // (Round 6 also tried the epilogue cut into its four channel groups and spread over the K steps of the next unit, the two waves of a SIMD at different
+    // points of the step: 5-25 % SLOWER per layer - the slice's branch splits the unrolled MFMA stream and every step then carries stores - so it is whole.)
+    f32x16 acc[NR];
+    auto epilogue = [&]() {
+        // (no early return for lanes outside the image: the lane exchange below needs every lane; their stores are masked)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                h4 rv[2], av[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const int r = 4 * (2 * k + qq) + j;
+                        f2 v, a;
+                        c8_enc_pair(F2(acc[n][r], acc[n][r + 1]), F2(bi[r], bi[r + 1]), F2(sc[r], sc[r + 1]), F2(sf[r], sf[r + 1]), actp, v, a);
+                        rv[qq][j] = (_Float16)v.x; rv[qq][j + 1] = (_Float16)v.y; av[qq][j] = (_Float16)a.x; av[qq][j + 1] = (_Float16)a.y;
+                    }
+                const u32x4 r16 = c8_pair16(rv[0], rv[1]);
+                if (pix_ok[n]) *reinterpret_cast<u32x4*>(rawh + obase[n] + (size_t)(2 * k) * ohw * 8) = r16;
+                if (twoOut) {
+                    const u32x4 a16 = c8_pair16(av[0], av[1]);
+                    if (pix_ok[n]) *reinterpret_cast<u32x4*>(acth + obase[n] + (size_t)(2 * k) * ohw * 8) = a16;
+                }
+            }
     };
 
     int du = unit0, dch = 0, cu = unit0, ch = 0;
-    set_dma_unit(unit0);
-    issue_dma(0, 0);
+    // LW = 0: a unit's epilogue stores are issued AFTER the DMA of the next step, and vmcnt is one in-order queue (loads, LDS-DMA and stores retire in issue order -
+    // the property srt_down1_stream_kernel is built on): "my pieces of step s have landed" is "at most the NST stores behind them are outstanding".
+    int pending = 0;                                           // store instructions this wave issued in the previous step (wave-uniform); stays 0 on a loader wave
+    if (loader) { set_dma_unit(unit0); issue_dma(0, 0, false); }
     for (int s = 0; s < nsteps; ++s) {
-        __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));               // this wave's pieces of step s have landed (and its older stores)
-        __syncthreads();                                       // everybody's have; everybody is past step s-1 (its stage is free)
-        if (s + 1 < nsteps) {
+        if (!(ABL & 32) || s == 0) {
+            if (loader) {                                      // this wave's pieces of step s have landed
+                if (pending == 4) __builtin_amdgcn_s_waitcnt(c8_vmcnt(4));
+                else if (pending == 2) __builtin_amdgcn_s_waitcnt(c8_vmcnt(2));
+                else __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));
+            }
+            __syncthreads();                                   // everybody's have; everybody is past step s-1 (its stage is free)
+        }
+        pending = 0;
+        if (loader && s + 1 < nsteps) {
             if (++dch == nch) { dch = 0; set_dma_unit(++du); }
-            issue_dma(dch, (s + 1) & 1);
+            issue_dma(dch, (s + 1) & 1, s >= 1);
         }
-        if (ch == 0) {
-            if (s > 0) epilogue();                             // the previous unit's stores go out in the shadow of the DMA just issued
-            set_out_unit(cu);
+        if (worker) {
+            if (ch == 0) {
+                if (s > 0 && !(ABL & 8)) {                     // the previous unit's stores go out in the shadow of the DMA just issued
+                    epilogue();
+                    if (!LW) pending = __builtin_amdgcn_ballot_w64(pix_ok[0]) != 0 ? (twoOut ? 4 : 2) : 0;   // (a wave with no lane inside the image skips the store instructions)
+                }
+                set_out_unit(cu);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        }
-        const _Float16* spatch = s_mem + (s & 1) * STAGE_H;
-        const _Float16* sw = spatch + PATCH_H;
+                for (int n = 0; n < NR; ++n)
 #pragma unroll
-        for (int tap = 0; tap < 25; ++tap) {
-            const int ky = tap / 5, kx = tap % 5;
-            const int koff = (ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)) * 8;
-            const h8 a = *reinterpret_cast<const h8*>(sw + tap * 512 + aoff);
-            const h8 b = *reinterpret_cast<const h8*>(spatch + boff + koff);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+            }
+            const _Float16* spatch = s_mem + (s & 1) * STAGE_H;
+            const _Float16* sw = spatch + PATCH_H;
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int tap = 0; tap < 25; ++tap) {
+                    const int ky = tap / 5, kx = tap % 5;
+                    const int koff = (ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)) * 8;
+                    h8 a;
+                    if (ABL & 16) { for (int q = 0; q < 8; ++q) a[q] = (_Float16)(float)(tap + lane); }
+                    else a = *reinterpret_cast<const h8*>(sw + tap * 512 + aoff);
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) {
+                        h8 b;
+                        if (ABL & 16) { for (int q = 0; q < 8; ++q) b[q] = (_Float16)(float)(s + q + n); }
+                        else b = *reinterpret_cast<const h8*>(spatch + boff[n] + koff);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+            if (++ch == nch) { ch = 0; ++cu; }
         }
-        if (++ch == nch) { ch = 0; ++cu; }
     }
-    epilogue();
+    if (loader) __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));
+    if (worker) epilogue();
 }
 
 // ------------------------------------------------------------------------------------------- decoder, C8 in -> C8 out (or planar out: up5)
-// Transposed 5x5 stride-2 convolution as four parity classes of the output (srt_nn3.hip: srt_dec_f16); one 32-pixel INPUT sub-tile per wave, all four
-// classes accumulated from one B fragment per input shift.  CS (up5, Cout = 16): class-stacked weights - 32 rows = 2 x-classes x 16 channels, 15 (ky, dx)
-// products per chunk, two accumulators (one per row class) - and planar fp16 stores (srt_up6_stream_kernel reads planar halves).
-template <int SW, int NSY, int NI, int ST, bool CS>
+// Transposed 5x5 stride-2 convolution as four parity classes of the output (srt_nn3.hip: srt_dec_f16); 32-pixel INPUT sub-tiles, all four classes accumulated
+// from one B fragment per input shift.  CS (up5, Cout = 16): class-stacked weights - 32 rows = 2 x-classes x 16 channels, 15 (ky, dx)
+// products per chunk, two accumulators (one per row class) - and planar fp16 stores (srt_up6_stream_kernel reads planar halves).  LW: see srt_enc_c8.
+template <int SW, int NSY, int NI, int ST, bool CS, int LW, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int tpw)
 {
-    static_assert(NSY * NI == 8 && 32 % SW == 0 && ST >= 2 && ST <= 4, "one 32-pixel sub-tile per wave");
+    static_assert(NSY * NI == 8 && 32 % SW == 0 && ST >= 2 && ST <= 4, "eight 32-pixel sub-tiles");
     constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
+    constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : 1;
     constexpr int PH = TH + 2, PC = TW + 2;
     constexpr int PLANE = NI * PH * PC;
-    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + 7) / 8;
-    constexpr int NT = CS ? 15 : 25, WPW = (NT + 7) / 8;       // NT pieces of 1 KiB: the two k-group rows of one tap (or (ky, dx) pair)
+    constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + NLW - 1) / NLW;
+    constexpr int NT = CS ? 15 : 25, WPW = (NT + NLW - 1) / NLW;   // NT pieces of 1 KiB: the two k-group rows of one tap (or (ky, dx) pair)
     constexpr int PATCH_H = NPP * 512, WSLAB_H = NT * 512, STAGE_H = PATCH_H + WSLAB_H;
-    constexpr int DPW = PPW + WPW;                             // DMA instructions per wave and step
+    constexpr int DPW = PPW + WPW;                             // DMA instructions per loader wave and step
     constexpr int NACC = CS ? 2 : 4;
     __shared__ __attribute__((aligned(16))) _Float16 s_mem[ST * STAGE_H];
     static_assert(sizeof(s_mem) <= 160 * 1024, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = !LW || wave >= 4, worker = !LW || wave < 4;
+    const int lw = LW ? (wave & 3) : wave;
     const int tilesX = (p.W + TW - 1) / TW, tilesY = (p.H + TH - 1) / TH, nsp = tilesX * tilesY;
     const int groups = (p.ntiles + NI - 1) / NI, nunits = nsp * groups;
     const int upw = (nunits + tpw - 1) / tpw, MBK = CS ? 1 : p.Cout / 32;
@@ -258,21 +376,21 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
     unsigned wvoff[WPW], wm0[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int piece = min(wave + 8 * i, NT - 1);
+        const int piece = min(lw + NLW * i, NT - 1);
         wvoff[i] = (unsigned)(((2 * piece + g) * CPW + l31) * 16);
         wm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PATCH_H * 2 + piece * 1024));
     }
     // patch slot e = ((gg * NI + il) * PH + r) * PC + col <- k-group gg of the chunk, instance tile0 + il, input row ty0 - 1 + r, column tx0 - 1 + col
     unsigned pvoff[PPW], pm0[PPW];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(wave + 8 * i, NPP - 1) * 1024));
+    for (int i = 0; i < PPW; ++i) pm0[i] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(min(lw + NLW * i, NPP - 1) * 1024));
     const unsigned nrec = (unsigned)min((size_t)0x7fffffff, (size_t)2 * NI * p.srcA_tile);     // srcA_tile == srcB_tile (launcher)
     const _Float16* pa = nullptr; const _Float16* pb = nullptr;
     auto set_dma_unit = [&](int unit) {
         const int sp = unit % nsp, tile0 = (unit / nsp) * NI, tx0 = (sp % tilesX) * TW, ty0 = (sp / tilesX) * TH;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int e = min(wave + 8 * i, NPP - 1) * 64 + lane;
+            const int e = min(lw + NLW * i, NPP - 1) * 64 + lane;
             const int gg = e / PLANE, rem = e % PLANE, col = rem % PC, r = (rem / PC) % PH, il = rem / (PC * PH);
             const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
             const bool ok = e < PITEMS && tile0 + il < p.ntiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
@@ -283,20 +401,30 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
     };
     const int chA = p.CA / 16;                                 // chunks [0, chA) read the skip tensor, the rest the previous decoder output
     const unsigned chunk_bytes = (unsigned)(32 * hw);
-    auto issue_dma = [&](int ch, int stage) {
+    auto issue_dma = [&](int ch, int stage, bool primed) {
         const unsigned sb = (unsigned)stage * (unsigned)(STAGE_H * 2);
         const bool fromA = ch < chA;
         const i32x4 rs = c8_rsrc(fromA ? pa : pb, nrec);
-        const unsigned soff = (unsigned)(fromA ? ch : ch - chA) * chunk_bytes;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(fromA ? ch : ch - chA) * chunk_bytes));
         const _Float16* ws = wp + (size_t)ch * cgStride;
+        if (!((ABL & 2) && primed)) {
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+            for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
+        }
+        if (!((ABL & 1) && primed)) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, soff, pm0[i] + sb);
+            for (int i = 0; i < PPW; ++i) c8_dma_buffer(pvoff[i], rs, soff, pm0[i] + sb);
+        }
     };
 
-    const int il_w = wave / NSY, sy = wave % NSY, a_l = sy * SH + l31 / SW, b_l = l31 % SW;
-    const int boff = (g * PLANE + (il_w * PH + a_l + 1) * PC + b_l + 1) * 8;
+    int boff[NR], il_w[NR], a_l[NR];
+    const int b_l = l31 % SW;
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int st = NR * (LW ? (wave & 3) : wave) + n;
+        il_w[n] = st / NSY; a_l[n] = (st % NSY) * SH + l31 / SW;
+        boff[n] = (g * PLANE + (il_w[n] * PH + a_l[n] + 1) * PC + b_l + 1) * 8;
+    }
     const int aoff = (g * 32 + l31) * 8;
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
@@ -308,102 +436,169 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
         bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
     }
     _Float16* outh = reinterpret_cast<_Float16*>(p.outAct);
-    size_t obase = 0; bool pix_ok = false;
+    size_t obase[NR]; bool pix_ok[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) { obase[n] = 0; pix_ok[n] = false; }
     auto set_out_unit = [&](int unit) {
-        const int sp = unit % nsp, tile = (unit / nsp) * NI + il_w, a = (sp / tilesX) * TH + a_l, b = (sp % tilesX) * TW + b_l;
-        pix_ok = tile < p.ntiles && a < p.H && b < p.W;
-        const size_t pix = pix_ok ? (size_t)(2 * a) * Wo + 2 * b : 0;
-        obase = stem * p.out_stem + (pix_ok ? tile : 0) * p.out_tile + (CS ? pix : ((size_t)(m0 / 8) * ohw + pix) * 8 + 4 * g);
+        const int sp = unit % nsp;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int tile = (unit / nsp) * NI + il_w[n], a = (sp / tilesX) * TH + a_l[n], b = (sp % tilesX) * TW + b_l;
+            pix_ok[n] = tile < p.ntiles && a < p.H && b < p.W;
+            const size_t pix = pix_ok[n] ? (size_t)(2 * a) * Wo + 2 * b : 0;
+            // C8 out: the lane stores output column 2 b + g of its pixel pair (c8_pair16).  CS (planar out): even lanes store channel 8 qq + 4 g + j of a pair
+            // (j, j + 1), odd lanes channel j + 1, four output columns 4 (b / 2) .. + 3 each
+            obase[n] = stem * p.out_stem + (pix_ok[n] ? tile : 0) * p.out_tile +
+                       (CS ? pix - (pix_ok[n] ? 2 * (b_l & 1) : 0) : ((size_t)(m0 / 8) * ohw + pix + (pix_ok[n] ? g : 0)) * 8);
+        }
     };
-    f32x16 acc[NACC];
+    f32x16 acc[NR][NACC];
     auto epilogue = [&]() {
-        if (!pix_ok) return;
-        if constexpr (CS) {
-            // rows of the MFMA tile: m = 8 q + 4 g + j = px * 16 + co  ->  px = q >> 1, co = 8 (q & 1) + 4 g + j
+        // (no early return for lanes outside the image: the lane exchanges need every lane; their stores are masked)
 #pragma unroll
-            for (int py = 0; py < 2; ++py)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r0 = 4 * qq + j, r1 = 4 * (qq + 2) + j, co = 8 * qq + 4 * g + j;
-                        const h2 hv = { (_Float16)srt_dec_epilogue(acc[py][r0], bi[r0], sc[r0], sf[r0], actp),
-                                        (_Float16)srt_dec_epilogue(acc[py][r1], bi[r1], sc[r1], sf[r1], actp) };
-                        *reinterpret_cast<h2*>(outh + obase + (size_t)co * ohw + (size_t)py * Wo) = hv;
-                    }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int n = 0; n < NR; ++n) {
+            if constexpr (CS) {
+                // rows of the MFMA tile: m = 8 q + 4 g + j = px * 16 + co  ->  px = q >> 1, co = 8 (q & 1) + 4 g + j: the two x-classes of a channel are one packed
+                // pair = two neighbouring output columns.  Neighbouring lanes (input columns b, b + 1) trade one channel each (DPP quad_perm [1, 0, 3, 2]): 8-byte stores.
+                const bool odd = (lane & 1) != 0;
 #pragma unroll
                 for (int py = 0; py < 2; ++py)
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        h4 v;
+                    for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (_Float16)srt_dec_epilogue(acc[py * 2 + px][4 * q + j], bi[4 * q + j], sc[4 * q + j], sf[4 * q + j], actp);
-                        *reinterpret_cast<h4*>(outh + obase + ((size_t)q * ohw + (size_t)py * Wo + px) * 8) = v;
+                        for (int j = 0; j < 4; j += 2) {
+                            unsigned d[2];
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const int r0 = 4 * qq + j + jj, r1 = 4 * (qq + 2) + j + jj;              // (bias / BN of r0 and r1 are the same channel's)
+                                const f2 o = c8_dec_pair(F2(acc[n][py][r0], acc[n][py][r1]), F2(bi[r0], bi[r1]), F2(sc[r0], sc[r1]), F2(sf[r0], sf[r1]), actp);
+                                const h2 hv = { (_Float16)o.x, (_Float16)o.y };
+                                d[jj] = __builtin_bit_cast(unsigned, hv);
+                            }
+                            const unsigned send = odd ? d[0] : d[1];                                   // the even lane's channel j + 1 value goes to the odd lane, the odd lane's channel j value to the even one
+                            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);
+                            const u32x2 v = odd ? (u32x2){ recv, d[1] } : (u32x2){ d[0], recv };
+                            const int co = 8 * qq + 4 * g + j + (odd ? 1 : 0);
+                            if (pix_ok[n]) *reinterpret_cast<u32x2*>(outh + obase[n] + (size_t)co * ohw + (size_t)py * Wo) = v;
+                        }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        h4 v[2];
+#pragma unroll
+                        for (int px = 0; px < 2; ++px)
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {
+                                const int r = 4 * q + j;
+                                const f2 o = c8_dec_pair(F2(acc[n][py * 2 + px][r], acc[n][py * 2 + px][r + 1]), F2(bi[r], bi[r + 1]), F2(sc[r], sc[r + 1]), F2(sf[r], sf[r + 1]), actp);
+                                v[px][j] = (_Float16)o.x; v[px][j + 1] = (_Float16)o.y;
+                            }
+                        const u32x4 o16 = c8_pair16(v[0], v[1]);
+                        if (pix_ok[n]) *reinterpret_cast<u32x4*>(outh + obase[n] + ((size_t)q * ohw + (size_t)py * Wo) * 8) = o16;
                     }
+            }
         }
     };
 
     int du = unit0, dch = 0, cu = unit0, ch = 0, issued = 0;
-    set_dma_unit(unit0);
-    auto issue_next = [&]() {                                  // the step after the last one issued (always exactly DPW instructions: past the end, step 0 of the last unit again - harmless, its stage is free)
-        issue_dma(dch, issued % ST);
+    constexpr int NST = 8;                                     // LW = 0: store instructions of one epilogue (C8 out: 4 groups x 2 rows of 16 B; planar out: 2 rows x 4 channel pairs of 8 B); pinned by tests/test_abi.py
+    bool pending = false;                                      // this wave issued them in the previous step (wave-uniform; never on a loader-only wave)
+    auto issue_next = [&]() {                                  // the step after the last one issued (always exactly DPW instructions: past the end, the last step again - harmless, its stage is free)
+        issue_dma(dch, issued % ST, issued >= ST);
         ++issued;
         if (issued < nsteps && ++dch == nch) { dch = 0; set_dma_unit(++du); }
     };
-    for (int i = 0; i < ST - 1; ++i) issue_next();
+    if (loader) {
+        set_dma_unit(unit0);
+        for (int i = 0; i < ST - 1; ++i) issue_next();
+    }
     for (int s = 0; s < nsteps; ++s) {
-        // everything older than this wave's pieces of the ST-2 newest steps has landed: step s (stores only make the wait longer: loads retire in order)
-        __builtin_amdgcn_s_waitcnt(c8_vmcnt((ST - 2) * DPW));
-        __syncthreads();
-        issue_next();                                          // step s + ST - 1 into the stage step s - 1 just left
-        if (ch == 0) {
-            if (s > 0) epilogue();
-            set_out_unit(cu);
-#pragma unroll
-            for (int c = 0; c < NACC; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        if (!(ABL & 32) || s == 0) {
+            if (loader) {
+                // everything older than this wave's pieces of the ST-2 newest steps has landed: step s (+ the NST epilogue stores of the previous step, issued
+                // behind its DMA: vmcnt retires in issue order, see srt_enc_c8)
+                if (pending) __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW + NST));
+                else __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW));
+            }
+            __syncthreads();
         }
-        const _Float16* spatch = s_mem + (s % ST) * STAGE_H;
-        const _Float16* sw = spatch + PATCH_H;
+        pending = false;
+        if (loader) issue_next();                              // step s + ST - 1 into the stage step s - 1 just left
+        if (worker) {
+            if (ch == 0) {
+                if (s > 0 && !(ABL & 8)) { epilogue(); if (!LW) pending = __builtin_amdgcn_ballot_w64(pix_ok[0]) != 0; }
+                set_out_unit(cu);
 #pragma unroll
-        for (int sh = 0; sh < 9; ++sh) {                       // shift-major: one B fragment per input shift
-            const int dy = sh / 3 - 1, dx = sh % 3 - 1;
-            const h8 b = *reinterpret_cast<const h8*>(spatch + boff + (dy * PC + dx) * 8);
+                for (int n = 0; n < NR; ++n)
 #pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const int py = (ky + 1) & 1;
-                if ((py + 1 - ky) / 2 != dy) continue;
-                if constexpr (CS) {
-                    const h8 a = *reinterpret_cast<const h8*>(sw + (ky * 3 + dx + 1) * 512 + aoff);
-                    acc[py] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[py], 0, 0, 0);
-                } else {
+                    for (int c = 0; c < NACC; ++c)
 #pragma unroll
-                    for (int kx = 0; kx < 5; ++kx) {
-                        const int px = (kx + 1) & 1;
-                        if ((px + 1 - kx) / 2 != dx) continue;
-                        const h8 a = *reinterpret_cast<const h8*>(sw + (ky * 5 + kx) * 512 + aoff);
-                        acc[py * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[py * 2 + px], 0, 0, 0);
+                        for (int r = 0; r < 16; ++r) acc[n][c][r] = 0.0f;
+            }
+            const _Float16* spatch = s_mem + (s % ST) * STAGE_H;
+            const _Float16* sw = spatch + PATCH_H;
+#pragma unroll
+            for (int sh = 0; sh < ((ABL & 4) ? 0 : 9); ++sh) { // shift-major: one B fragment per sub-tile and input shift
+                const int dy = sh / 3 - 1, dx = sh % 3 - 1;
+                h8 b[NR];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    if (ABL & 16) { for (int q = 0; q < 8; ++q) b[n][q] = (_Float16)(float)(s + q + lane + n); }
+                    else b[n] = *reinterpret_cast<const h8*>(spatch + boff[n] + (dy * PC + dx) * 8);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int py = (ky + 1) & 1;
+                    if ((py + 1 - ky) / 2 != dy) continue;
+                    if constexpr (CS) {
+                        h8 a;
+                        if (ABL & 16) { for (int q = 0; q < 8; ++q) a[q] = (_Float16)(float)(ky + lane); }
+                        else a = *reinterpret_cast<const h8*>(sw + (ky * 3 + dx + 1) * 512 + aoff);
+#pragma unroll
+                        for (int n = 0; n < NR; ++n) acc[n][py] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n], acc[n][py], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) {
+                            const int px = (kx + 1) & 1;
+                            if ((px + 1 - kx) / 2 != dx) continue;
+                            h8 a;
+                            if (ABL & 16) { for (int q = 0; q < 8; ++q) a[q] = (_Float16)(float)(ky * 5 + kx + lane); }
+                            else a = *reinterpret_cast<const h8*>(sw + (ky * 5 + kx) * 512 + aoff);
+#pragma unroll
+                            for (int n = 0; n < NR; ++n) acc[n][py * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n], acc[n][py * 2 + px], 0, 0, 0);
+                        }
                     }
                 }
             }
+            if (++ch == nch) { ch = 0; ++cu; }
         }
-        if (++ch == nch) { ch = 0; ++cu; }
     }
-    __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));                   // the tail's harmless extra DMA must not outlive the workgroup's LDS
-    epilogue();
+    if (loader) __builtin_amdgcn_s_waitcnt(c8_vmcnt(0));       // the tail's harmless extra DMA must not outlive the workgroup's LDS
+    if (worker) epilogue();
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
-static int c8_target_wgs()
+#ifdef SRT_TUNING
+static int c8_abl() { const char* t = getenv("SRT_TUNE_C8"); return t ? atoi(t) : 0; }
+#define C8_ABL_CASES(X) X(3) X(4) X(8) X(16) X(12)
+#endif
+static int c8_env(const char* name, int dflt)
 {
-    static int v = -1;
-    if (v < 0) { const char* t = getenv("SPLEETERRT_C8_WGS"); v = t ? atoi(t) : 0; if (v <= 0) v = 1024; }
-    return v;
+    const char* t = getenv(name);
+    return t ? atoi(t) : dflt;
 }
+static int c8_target_wgs() { static const int v = c8_env("SPLEETERRT_C8_WGS", 1024) > 0 ? c8_env("SPLEETERRT_C8_WGS", 1024) : 1024; return v; }
+// The loader-wave form (LW = 1) measured SLOWER on every layer but down5 / down6 (round 6, same box: 5-stem step 5.26 vs 5.09 ms; up4 0.434 vs 0.385): with one
+// computing wave per SIMD the MFMA stream loses more to its own LDS-read latency than the other waves lose to the DMA issue.  It is compiled into the tuning
+// library only (SRT_TUNE_C8LW=1); the product instantiates LW = 0.
+#ifdef SRT_TUNING
+static bool c8_lw() { static const bool v = c8_env("SRT_TUNE_C8LW", 0) != 0; return v; }
+#define C8_LW(then_, else_) do { if (c8_lw()) { then_; } else { else_; } } while (0)
+#else
+#define C8_LW(then_, else_) do { else_; } while (0)
+#endif
 // units per workgroup: about c8_target_wgs() workgroups per launch (4 rounds of the 256 CUs), never across a (stem, M block) boundary
 static int c8_tpw(int nunits, int pairs)
 {
@@ -419,11 +614,17 @@ int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s)
     if (Wo > 16) {
         constexpr int TH = 8, TW = 32, NI = 1;
         const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
-        SRT_LAUNCH((srt_enc_c8<32, 8, 1>), dim3((unsigned)(((nunits + tpw - 1) / tpw) * pairs)), dim3(512), 0, s, p, tpw);
+        const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
+#ifdef SRT_TUNING
+#define C8_ENC_CASE(A) if (c8_abl() == A) { SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
+        C8_ABL_CASES(C8_ENC_CASE)
+#endif
+        C8_LW(SRT_LAUNCH((srt_enc_c8<32, 8, 1, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0>), grid, dim3(512), 0, s, p, tpw));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
         const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
-        SRT_LAUNCH((srt_enc_c8<16, 2, 4>), dim3((unsigned)(((nunits + tpw - 1) / tpw) * pairs)), dim3(512), 0, s, p, tpw);
+        const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
+        C8_LW(SRT_LAUNCH((srt_enc_c8<16, 2, 4, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_enc_c8<16, 2, 4, 0>), grid, dim3(512), 0, s, p, tpw));
     }
     return srt_launch_status();
 }
@@ -438,14 +639,18 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
         constexpr int TH = 8, TW = 32, NI = 1;
         const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
-        if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true>), grid, dim3(512), 0, s, p, tpw);
-        else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false>), grid, dim3(512), 0, s, p, tpw);
+#ifdef SRT_TUNING
+#define C8_DEC_CASE(A) if (c8_abl() == A) { if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0, A>), grid, dim3(512), 0, s, p, tpw); else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
+        C8_ABL_CASES(C8_DEC_CASE)
+#endif
+        if (cs) C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0>), grid, dim3(512), 0, s, p, tpw));
+        else C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
         const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
-        if (cs) SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true>), grid, dim3(512), 0, s, p, tpw);
-        else SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false>), grid, dim3(512), 0, s, p, tpw);
+        if (cs) C8_LW(SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true, 0>), grid, dim3(512), 0, s, p, tpw));
+        else C8_LW(SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     }
     return srt_launch_status();
 }

@@ -200,3 +200,49 @@ def test_down1_stream_store_count_matches_its_vmcnt_wait(tmp_path):
         assert 2 * stores_per_group in waits and stores_per_group in waits, (mangled, waits)
         dma = [l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]
         assert len(dma) >= 3                                                               # the LDS-DMA pieces the wait is about
+
+
+def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
+    """The C8-form fp16 kernels (csrc/srt_nn5.hip) prove "my LDS-DMA pieces of this step have landed" with s_waitcnt vmcnt(pieces still allowed in flight + NST), NST =
+    the store instructions of the epilogue a wave issued behind the previous step's DMA (vmcnt retires in issue order).  An NST above the real count would let
+    a step read a stage before its DMA landed.  Pinned on the ISA of every shipped instantiation: stores per epilogue copy (the epilogue is emitted twice: in the K-step
+    loop and for the workgroup's last unit), their width, no scratch, and the counted wait immediates.  (LW = 1 instantiations: the DMA is issued by loader-only waves
+    that never store, so only the ring-depth wait exists there.)"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "spleeterrt_amd", "csrc")
+    asm = tmp_path / "nn5.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "srt_nn5.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = asm.read_text().split("\n")
+    kernels = [m.group(1) for m in (re.match(r"(_Z10srt_(?:enc|dec)_c8I\w+):", l) for l in txt) if m]
+    assert len(kernels) == 6, kernels                       # 2 tile shapes x (encoder, decoder C8 out, decoder planar out); the LW = 1 forms exist in the tuning library only
+    for mangled in kernels:
+        start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
+        end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
+        body = [l.strip() for l in txt[start:end] if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
+        meta = [l for l in txt[start:end] if ".amdhsa_private_segment_fixed_size" in l]
+        assert meta and meta[0].split()[-1] == "0", (mangled, meta)
+        assert not [l for l in body if l.startswith("scratch_")]
+        stores = [l.split()[0] for l in body if l.startswith("global_store") or l.startswith("buffer_store")]
+        waits = sorted(set(int(m) for l in body if l.startswith("s_waitcnt") for m in re.findall(r"vmcnt\((\d+)\)", l)))
+        targs = [int(x) for x in re.findall(r"L[ib](\d+)E", mangled)]
+        enc = "srt_enc_c8" in mangled
+        sw, lw = targs[0], targs[3] if enc else targs[5]
+        nr = 2 if lw else 1                                 # sub-tiles (hence epilogue copies of the stores) per computing wave
+        if enc:                                             # raw + act: 2 + 2 sixteen-byte stores per sub-tile and epilogue
+            assert stores == ["global_store_dwordx4"] * (8 * nr), (mangled, stores)
+            if not lw:                                      # LW = 0: the wait allows the 4 (2 without the act copy: down6) stores behind the DMA
+                assert 4 in waits and 2 in waits and 0 in waits, (mangled, waits)
+        else:
+            planar_out = targs[4] == 1
+            assert stores == ["global_store_dwordx2" if planar_out else "global_store_dwordx4"] * (16 * nr), (mangled, stores)
+            nlw = 4 if lw else 8
+            npp = {32: 11, 16: 14}[sw]                      # patch pieces of 1 KiB per stage
+            dpw = -(-npp // nlw) + -(-(15 if planar_out else 25) // nlw)     # DMA instructions per loader wave and K step
+            assert dpw in waits, (mangled, dpw, waits)      # ring depth 3: one step's pieces may stay in flight
+            if not lw:
+                assert dpw + 8 in waits, (mangled, waits)   # ... + the NST = 8 epilogue stores issued behind them
+        assert len([l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]) >= 2
