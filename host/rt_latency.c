@@ -112,7 +112,9 @@ int main(int argc, char **argv)
         double *ord = (double *)malloc(sizeof(double) * (size_t)hops), *join = (double *)malloc(sizeof(double) * (size_t)hops);
         int no = 0, nj = 0;
         for (int h = 0; h < hops; ++h) { if ((h + 1) % T == 0) join[nj++] = j->us[h]; else ord[no++] = j->us[h]; }    /* hop h+1 completes a batch */
-        fprintf(f, "%s{\"init_ms\": %.1f, \"init_error\": \"%s\", \"output_peak\": %.6g, ", i ? ", " : "", j->init_ms, j->init_error, j->peak);
+        int worst = 0;
+        for (int h = 1; h < hops; ++h) if (j->us[h] > j->us[worst]) worst = h;                                        /* which call was the slowest: the first ones (warm-up) or one next to a batch boundary */
+        fprintf(f, "%s{\"init_ms\": %.1f, \"init_error\": \"%s\", \"output_peak\": %.6g, \"worst_hop\": %d, ", i ? ", " : "", j->init_ms, j->init_error, j->peak, worst);
         stats(f, "ordinary_hops", ord, no); fprintf(f, ", "); stats(f, "join_hops", join, nj);
         fprintf(f, "}");
         free(ord); free(join);

@@ -173,6 +173,23 @@ void Spleeter4StemsInit(Spleeter4Stems* msr, int F, int T, void* coeffProvider[4
         INITTRY(hipMemcpy(s->d_tw, tw.data(), 2 * FFTSIZE * 4, hipMemcpyHostToDevice));
         INITTRY(hipHostMalloc((void**)&s->pinned, 2 * OUTPUTSEG * 8 * sizeof(float), hipHostMallocDefault));   // pinned queue for the per-hop D2H copy
         INITTRY(hipStreamSynchronize(nullptr));               // masks / windows / twiddles (null-stream copies) are in place before the first hop
+        // Pre-warm the per-hop path too: the first launch of the two hop kernels loads their code, and eight plugin instances making their first call at
+        // the same time queued behind each other for it - the slowest call of every instance was its FIRST one, 7.5 ms (round 6, host/rt_latency.c
+        // `worst_hop`).  One hop on silence here, on this thread: zero ring, zero spectrum, unit masks - every buffer it writes stays zero.
+        INITTRY(hipMemsetAsync(s->d_ring, 0, sizeof s->ring, s->hop));
+        {
+            SrtStreamHop p; memset(&p, 0, sizeof p);
+            const size_t rowF2 = SRT_SPEC_LD;
+            p.ring = s->d_ring; p.inPos = 0;
+            p.specRow = s->d_spec; p.specChStride = (size_t)s->T * rowF2;
+            p.magRow = s->d_mag; p.magChStride = s->hw;
+            p.maskRow = s->d_masks; p.maskStemStride = 2 * s->hw; p.maskChStride = s->hw;
+            p.F = s->F; p.overlap = s->d_overlap; p.out = s->d_out;
+            p.analysisWnd = s->d_awin; p.synthesisWnd = s->d_swin; p.twiddle = s->d_tw;
+            if (srt_launch_stream_hop(p, s->hop)) { stream_fail("Spleeter4StemsInit(hop pre-warm)", "kernel launch failed"); return; }
+            INITTRY(hipMemcpyAsync(s->pinned, s->d_out, OUTPUTSEG * 8 * sizeof(float), hipMemcpyDeviceToHost, s->hop));
+            INITTRY(hipStreamSynchronize(s->hop));
+        }
 #undef INITTRY
         s->outq[0] = s->pinned; s->outq[1] = s->pinned + OUTPUTSEG * 8;
     }

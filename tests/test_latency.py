@@ -12,9 +12,9 @@ between calls).  The WORST call of every run must stay under the hop period itse
 isolated ~1 ms spikes, host scheduling).  Initialisation (weight upload, packing, workspace allocation, hipGraph capture) is timed
 separately and is NOT part of any call.  Two more runs drive EIGHT instances at once (eight plugin instances in one DAW on one GPU; nothing
 batches their hops across instances - each owns its hop stream and its network stream).  Paced at the real hop period - the situation the contract
-is about - every call of every instance, the worst one included, must stay under the hop period.  Back to back (an artificial burst no host
-produces: eight network batches collide with every instance's hops) p99 must stay under the hop period; the single worst call of that run is
-INFORMATIONAL: it is recorded (`worst_call_us`) and only has to show that nothing hangs.  The numbers go to gpurun_out/r05_latency.json
+is about - every call of every instance, the worst one included, must stay under 5 ms (a fifth of the hop period: a host with its own DSP in the callback
+keeps the rest), ordinary hops p99 under 2 ms.  Back to back (an artificial burst no host produces: eight network batches collide with every instance's
+hops) p99 must stay under 5 ms and the single worst call under 10 ms (recorded as `worst_call_us`).  The numbers go to gpurun_out/r06_latency.json
 (copied to profiles/)."""
 import json
 import os
@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "host")
 F, T = 1536, 256
 ORDINARY_P99_US, JOIN_P99_US = 2000.0, 5000.0
+EIGHT_PACED_WORST_US = 5000.0                                  # every call of eight paced instances (measured <= 0.5 ms)
+EIGHT_BURST_WORST_US = 10000.0                                 # every call of eight instances called back to back (measured <= 2 ms; under half a hop period)
 HOP_US = 1024 / 44100 * 1e6
 
 
@@ -57,16 +59,19 @@ def test_streaming_call_latency_two_instances(tmp_path, coeffs):
                 assert j["p99_us"] < JOIN_P99_US, "%s instance %d join hops: %r" % (tag, i, j)
                 assert max(o["max_us"], j["max_us"]) < HOP_US, "%s instance %d: a call took longer than a hop period: %r %r" % (tag, i, o, j)
             elif pace:                                         # eight instances paced like eight plugins in one host: the contract proper, worst call included
-                assert max(o["max_us"], j["max_us"]) < HOP_US, "%s instance %d: a call took longer than a hop period: %r %r" % (tag, i, o, j)
-                assert o["p99_us"] < JOIN_P99_US, "%s instance %d ordinary hops: %r" % (tag, i, o)
-            else:                                              # eight un-batched instances, no pacing: p99 is asserted, the worst call is informational
-                assert o["p99_us"] < HOP_US and j["p99_us"] < HOP_US, "%s instance %d: %r %r" % (tag, i, o, j)
+                # round 6: 0.37-0.50 ms worst call on every instance (round 5: 8.2-11.1 ms - each instance's FIRST call, loading the hop kernels' code behind
+                # seven other instances doing the same; Init pre-warms the hop path now, and the hop stream runs at the device's highest priority)
+                assert max(o["max_us"], j["max_us"]) < EIGHT_PACED_WORST_US, "%s instance %d: worst call above %g us: %r %r" % (tag, i, EIGHT_PACED_WORST_US, o, j)
+                assert o["p99_us"] < ORDINARY_P99_US, "%s instance %d ordinary hops: %r" % (tag, i, o)
+                assert j["p99_us"] < JOIN_P99_US, "%s instance %d join hops: %r" % (tag, i, j)
+            else:                                              # eight un-batched instances, no pacing (an artificial burst no host produces)
+                assert o["p99_us"] < JOIN_P99_US and j["p99_us"] < JOIN_P99_US, "%s instance %d: %r %r" % (tag, i, o, j)
                 worst = max(o["max_us"], j["max_us"])
                 r["worst_call_us"] = max(r.get("worst_call_us", 0.0), worst)
-                assert worst < 1e6, "%s instance %d: a call took more than a second (hang?): %r %r" % (tag, i, o, j)
+                assert worst < EIGHT_BURST_WORST_US, "%s instance %d: worst call above %g us (round 6 measured <= 2 ms): %r %r" % (tag, i, EIGHT_BURST_WORST_US, o, j)
             if hops > 2 * T:
                 assert inst["output_peak"] > 1e-4              # the stream is past its 2T hops of silence: real audio came out
     print("latency:", json.dumps(record["runs"]))
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        json.dump(record, open(os.path.join(d, "r05_latency.json"), "w"), indent=1)
+        json.dump(record, open(os.path.join(d, "r06_latency.json"), "w"), indent=1)
