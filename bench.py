@@ -198,7 +198,11 @@ def make_line(a, rec):
     for name, ms in tim:
         per.setdefault(name, []).append(ms)
     # per STEP: a layer that goes out as several launches (down1 of five sub-networks: a stack of four + one) counts with their sum
-    avg = {k: float(np.sum(v)) / a.steps for k, v in per.items()}
+    # (the divisor is the number of passes the timing log really holds - a saturated log (SRT_TIMING_MAX launches) or a native-host window that is not
+    # exactly `steps` passes would otherwise under-report every kernel silently)
+    passes = len(per.get("stft", [])) or a.steps
+    assert nocheck or passes == a.steps, "timing log holds %d passes of the step, %d were asked for (log saturated?)" % (passes, a.steps)
+    avg = {k: float(np.sum(v)) / passes for k, v in per.items()}
     inst = stems * a.tiles
     nn_ms = sum(v for k, v in avg.items() if k in LAYER_FLOP or k == "actcopy")      # actcopy: the fallback bn+act pass in front of the first Winograd-form encoder layer (normally its producer writes the copy)
     nn_flop = FLOP_PER_PIXEL * T * F * inst
@@ -520,6 +524,7 @@ def measure_native(a, stems):
     e0.L, e0.h = lib, C.c_void_p(lib.srtMultiEngine(m, 0))
     tim = e0.get_timing()
     kern = e0.get_timing_kernels()
+    e0.set_timing(False)                                       # (srtMultiBenchResident leaves engine 0's timing window open for this read-out; close it)
     e0.h = None
     n = a.tiles * T * HOP
     text = info.value.decode()

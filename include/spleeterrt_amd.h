@@ -161,6 +161,8 @@ SRT_API srt_engine *srtMultiEngine(srt_multi *m, int g);
  * synchronises its device.  *seconds = first worker released -> last worker done.  seconds_events (may be NULL): the same K passes once more with
  * per-launch HIP events switched on for engine 0 (read them with srtGetTiming(srtMultiEngine(m, 0), ...); timing stays on). */
 SRT_API int  srtMultiBenchResident(srt_multi *m, int tiles, int steps, int warmup, double *seconds, double *seconds_events);
+/* (with seconds_events != NULL the per-launch timing window of engine 0 stays OPEN after the call so that srtGetTiming / srtGetTimingKernels on
+ * srtMultiEngine(m, 0) can read the K event-timed passes; the caller closes it with srtSetTiming(engine, 0)) */
 
 /* debug / measurement */
 SRT_API int  srtCopyTensor(srt_engine *e, const char *name, int stem, int tile, float *h_dst, size_t max_floats); /* "conv1".."conv6","act1".."act5","up1".."up6" */

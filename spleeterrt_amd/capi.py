@@ -231,9 +231,12 @@ class Engine:
         out = np.empty((stems, 2, self.L.srtIstftLength(self.L.srtStftRows(L.size))), np.float32)
         try:
             self._chk(self.L.srtSeparateCliHost(self.h, C.c_void_p(L.ctypes.data), C.c_void_p(R.ctypes.data), L.size, stems, C.c_void_p(out.ctypes.data)))
-        finally:
+        except EngineError:
             if not keep_staging:
-                self.L.srtReleaseStaging(self.h)
+                self.L.srtReleaseStaging(self.h)              # best effort: the separation's own error is the one to report
+            raise
+        if not keep_staging:
+            self._chk(self.L.srtReleaseStaging(self.h))
         return out
 
     def separate_host_stream(self, L, R, frames=None, rows=None, out=None, pinned=False):

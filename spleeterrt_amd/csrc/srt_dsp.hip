@@ -16,6 +16,7 @@
 // sample is written once (see srt_istft_ola_kernel).
 #include "srt_internal.h"
 #include "srt_device.h"
+#include <stdlib.h>
 
 #define FFT_EX1_LD 272      // exchange-1 row stride (cf): 272*2 dwords = 32 (mod 64) -> conflict-free b64 reads
 #define FFT_EX2_LD 257      // exchange-2 row stride (cf): odd -> conflict-free strided b64 writes
@@ -187,6 +188,30 @@ __device__ __forceinline__ void fft4096_pp(cf (&v)[16], cf* e1, cf* e2, const cf
 // owns segments [s0, s1) recomputes the three frames before s0 as warm-up ((G+3)/G extra work).
 // The loop body is straight-line: the next frame's rows are prefetched from a CLAMPED frame index (a redundant reload
 // at the very end instead of a conditional assignment, which costs a register copy per staged value at every merge).
+// Cross-stem ratio mask folded into the inverse transform's prologue (srt_config.ratio_mask): instead of a separate read-modify-write pass over every
+// stem's masks (srt_ratio_mask_kernel: 2 x 0.5 GB at the bench shape), the workgroup that applies stem s's mask to a bin reads the OTHER stems' mask values of that bin
+// too (its S-1 neighbours on the XCD read the same rows at the same time: L2 hits) and normalises in registers.  Same arithmetic in the same order as
+// srt_ratio_mask_kernel (squares summed over stems ascending, (m_s^2 + eps/S) / (sum + eps)), so srtSeparate with ratio_mask equals srtRatioMask + srtIstft bit for bit.
+// own: the stem's raw mask value (already loaded); row0: mask row of stem 0 for this (tile, channel, frame); sstride: floats between stems.
+#pragma clang fp contract(off)     // (HIP's __fmul_rn / __fadd_rn are plain operators: only this keeps the compiler from fusing square and sum)
+__device__ __forceinline__ float srt_ratio_of(float own, const float* __restrict__ row0, size_t sstride, int nstems, int stem, int k)
+{
+    // (plain operators under contract(off): the square is rounded before it is added, exactly as in srt_ratio_mask_kernel.  HIP's __fmul_rn / __fadd_rn would
+    // not do: they are inline `x * y` / `x + y` from a header compiled with contraction on, and fuse after inlining.)
+    float sum = 0.0f;
+    const float mine = own * own;
+    for (int s = 0; s < nstems; ++s) {
+        const float v = row0[(size_t)s * sstride + k];
+        const float sq = v * v;
+        sum = sum + (s == stem ? mine : sq);
+    }
+    const float eps = 1e-10f, e1 = eps / (float)nstems;
+    return (mine + e1) / (sum + eps);
+}
+
+#pragma clang fp contract(fast)
+
+template <bool RATIO = false>
 __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftParams p, int G)
 {
     // 1-D launch in XCD order, stem fastest: the nstems workgroups that walk the SAME run of frames sit next to each other on
@@ -256,6 +281,18 @@ __global__ void __launch_bounds__(256, 2) srt_istft_ola_kernel(const SrtIstftPar
         if (f < p.frames) {                             // workgroup-uniform; false only for the last three segments of the stream
             // staging into sx: its last readers (exchange 1 of the previous frame, when it was `sy`) all passed that frame's
             // second barrier; the first barrier below also orders the twiddle table written before the loop
+            if constexpr (RATIO) {
+                if (has_mask && p.ratio) {               // normalise this frame's mask values across the stems (they arrived with the spectrum rows)
+                    const int tile = f / p.T, t = f % p.T;
+                    const float* r0 = p.masks + ((size_t)tile * 2) * tf + (size_t)t * p.F;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int km = min(min(tid + 256 * j, 2048), p.F - 1);
+                        gl[j] = srt_ratio_of(gl[j], r0, (size_t)p.ntiles * 2 * tf, p.nstems, stem, km);
+                        gr[j] = srt_ratio_of(gr[j], r0 + tf, (size_t)p.ntiles * 2 * tf, p.nstems, stem, km);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const int k = tid + 256 * j;
@@ -418,8 +455,8 @@ __global__ void __launch_bounds__(256, 3) srt_stft_kernel(const SrtStftParams p,
 }
 
 // NM: mask rows cover bins < F <= 256 NM, so only the first NM of a thread's eight bins can carry a mask value (F = 1024: 4 prefetch registers per channel instead of 8)
-template <int NM>
-__global__ void __launch_bounds__(256, 3) srt_istft_ola3_kernel(const SrtIstftParams p, int G)
+template <int NM, bool RATIO = false>
+__global__ void __launch_bounds__(256, RATIO ? 2 : 3) srt_istft_ola3_kernel(const SrtIstftParams p, int G)
 {
     const int pos = srt_xcd_order(gridDim.x), stem = pos % p.nstems, run = pos / p.nstems;       // stem fastest: the stems of a run share the spectrum rows in L2
     __shared__ cf s_mem[FFT_SMEM_F2 + FFT_MIR_F2 + FFT_TWB_F2];
@@ -459,7 +496,10 @@ __global__ void __launch_bounds__(256, 3) srt_istft_ola3_kernel(const SrtIstftPa
         }
         sl8 = specL[2048]; sr8 = specR[2048];
     };
-    // the 16 synthesis-window taps of this thread (samples tid + 256 k2) are rebuilt per frame from two registers: cos / sin of th = 2 pi (tid + 1/2) / 4096, over 3
+    // the 16 synthesis-window taps of this thread (samples tid + 256 k2) are rebuilt per frame from two registers: cos / sin of th = 2 pi (tid + 1/2) / 4096, over 3.
+    // (A deviation from the table the F > 1024 kernel reads - postWin, which reproduces InitSTFT's rounding: 1/3 - cos/3 in fp32 is off by up to ~3e-8 absolute,
+    // which is a large RELATIVE error only on the ~1e-7 taps at the window's edges.  tests/test_gpu_parity.py::test_istft_three_per_cu_kernel_against_the_table_kernel
+    // bounds the two kernels against each other on identical input at 5e-7 of the output's peak (measured 3.1e-7).)
     float ws3, wc3;
     sincospif((tid + 0.5f) * (1.0f / 2048.0f), &ws3, &wc3);
     ws3 *= 1.0f / 3.0f; wc3 *= 1.0f / 3.0f;
@@ -485,6 +525,18 @@ __global__ void __launch_bounds__(256, 3) srt_istft_ola3_kernel(const SrtIstftPa
             // G = F'_L + i F'_R, F' = re - i im, Hermitian-extended; kept swapped (im, re): inverse-by-forward trick.  Bins k = tid + 256 j < 2048 are this
             // thread's own transform inputs n2 = j; their partners 4096 - k go through `mir` to thread 256 - tid (slot 15 - j).
             cf v[16];
+            if constexpr (RATIO) {
+                if (has_mask && p.ratio) {               // (see srt_ratio_of; the extra loads are why this instantiation is built for two workgroups per CU)
+                    const int tile = f / p.T, t = f % p.T;
+                    const float* r0 = p.masks + ((size_t)tile * 2) * tf + (size_t)t * p.F;
+#pragma unroll
+                    for (int j = 0; j < NM; ++j) {
+                        const int km = min(tid + 256 * j, p.F - 1);
+                        gl[j] = srt_ratio_of(gl[j], r0, (size_t)p.ntiles * 2 * tf, p.nstems, stem, km);
+                        gr[j] = srt_ratio_of(gr[j], r0 + tf, (size_t)p.ntiles * 2 * tf, p.nstems, stem, km);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = tid + 256 * j;
@@ -549,7 +601,10 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     const int blocks = (nseg + G - 1) / G;
     // one stem per workgroup: 32 accumulator + 54 prefetch registers + the FFT fit in 256 VGPRs at 2 workgroups per CU
     // F > 1024: eight mask registers per channel do not fit the 168-VGPR budget of the three-per-CU form (22 dwords would spill): the two-per-CU kernel
-    if (p.F > 1024) SRT_LAUNCH(srt_istft_ola_kernel, dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    if (p.ratio && p.masks && p.nstems > 1) {            // cross-stem ratio mask applied in the prologue (srt_ratio_of)
+        if (p.F > 1024) SRT_LAUNCH((srt_istft_ola_kernel<true>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+        else SRT_LAUNCH((srt_istft_ola3_kernel<4, true>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    } else if (p.F > 1024) SRT_LAUNCH((srt_istft_ola_kernel<false>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     else SRT_LAUNCH((srt_istft_ola3_kernel<4>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     return srt_launch_status();
 }
@@ -626,33 +681,37 @@ int srt_launch_carry(float* out, size_t plane_len, int nplanes, size_t tail, flo
 
 // Cross-stem ratio mask (what official Spleeter applies and the reference deliberately leaves out, README.MD:82-85):
 // every stem's mask is squared and normalised by the sum over stems at the same (tile, channel, frame, bin).
+#pragma clang fp contract(off)
 __global__ void __launch_bounds__(256) srt_ratio_mask_kernel(float* masks, int nstems, size_t count)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= count) return;                                        // count is a multiple of 4 (F % 64 == 0)
-    float4 m[SRT_MAX_STEMS];
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every operation individually rounded (plain operators under contract(off), no fused multiply-add): srt_ratio_of, the form folded into the inverse transform's prologue,
+    // does the same operations in the same order, and the two must agree bit for bit (tests/test_gpu_parity.py::test_ratio_mask)
+    float m[SRT_MAX_STEMS][4];
+    float sum[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
     for (int s = 0; s < SRT_MAX_STEMS; ++s) {
         if (s < nstems) {
-            float4 v = *reinterpret_cast<const float4*>(masks + (size_t)s * count + i);
-            v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
-            m[s] = v;
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            const float4 v = *reinterpret_cast<const float4*>(masks + (size_t)s * count + i);
+            const float x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { m[s][c] = x[c] * x[c]; sum[c] = sum[c] + m[s][c]; }
         }
     }
     const float eps = 1e-10f, e1 = eps / (float)nstems;
 #pragma unroll
     for (int s = 0; s < SRT_MAX_STEMS; ++s) {
         if (s < nstems) {
-            float4 v = m[s];
-            v.x = (v.x + e1) / (sum.x + eps); v.y = (v.y + e1) / (sum.y + eps);
-            v.z = (v.z + e1) / (sum.z + eps); v.w = (v.w + e1) / (sum.w + eps);
+            float4 v;
+            v.x = (m[s][0] + e1) / (sum[0] + eps); v.y = (m[s][1] + e1) / (sum[1] + eps);
+            v.z = (m[s][2] + e1) / (sum[2] + eps); v.w = (m[s][3] + e1) / (sum[3] + eps);
             *reinterpret_cast<float4*>(masks + (size_t)s * count + i) = v;
         }
     }
 }
 
+#pragma clang fp contract(fast)
 int srt_launch_ratio_mask(float* masks, int nstems, size_t count, hipStream_t s)
 {
     if (!count || nstems < 1) return 0;

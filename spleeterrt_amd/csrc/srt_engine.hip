@@ -520,8 +520,11 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                     SrtConvParams q = p;
                     q.nstems = 4; q.stack = 4; q.CP2 = 64; q.wpack2 = e->wpack2_d1; q.wpack2_stem = 0;
                     if (srt_launch_pack_stemstack(q.wraw, SRT_COEFF_STRIDE, 4, e->wpack2_d1, L.cin, L.cout, q.CP2, e->stream)) return fail(-2, "pack launch failed");
-                    { TimerScope tg(e, "down1"); const int rg = srt_launch_enc2(q, e->stream); if (rg) return fail(-2, "encoder launch failed"); }
+                    { TimerScope tg(e, "down1"); const int rg = srt_launch_enc2(q, e->stream);
+                      if (rg == 1) return fail(-4, "internal: stem-stacked down1 group not covered by its launcher");
+                      if (rg) return fail(-2, "encoder launch failed"); }
                     p.nstems -= 4; p.elu_mask >>= 4;
+                    p.wpack += 4 * p.wpack_stem;                                 // (the per-stem packs advance with the group too - the remainder launch's fallbacks read them)
                     p.wraw += 4 * (size_t)SRT_COEFF_STRIDE; p.bias += 4 * (size_t)SRT_COEFF_STRIDE;
                     if (p.bnShift) { p.bnShift += 4 * (size_t)SRT_COEFF_STRIDE; p.bnScale += 4 * (size_t)SRT_COEFF_STRIDE; }
                     p.outRaw = eoff(e, p.outRaw, 4 * p.out_stem);
@@ -721,7 +724,10 @@ int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* 
     return srtStftEx(e, d_L, d_R, n, srtStftFrames(n), srtStftRows(n), d_spec, d_mag);
 }
 
-int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out)
+static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio);
+// (the public entry applies the masks as they are given: srtRatioMask is its caller's business)
+int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out) { return istft_issue(e, d_spec, rows, d_masks, d_out, false); }
+static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio)
 {
     if (!e || !d_spec || !d_out) return fail(-1, "srtIstft: null argument");
     DeviceScope ds(e->device);
@@ -733,6 +739,7 @@ int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_mas
     p.frames = (int)rows; p.masks = d_masks; p.nstems = e->cfg.n_stems; p.ntiles = (int)((rows + T - 1) / T);
     p.T = T; p.F = e->cfg.F;
     for (int s = 0; s < SRT_MAX_STEMS; ++s) p.oob[s] = e->cfg.oob_weight[s];
+    p.ratio = ratio ? 1 : 0;
     p.frames_out = nullptr; p.out = d_out; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
     TimerScope ts(e, "istft");
     if (srt_launch_istft(p, e->stream)) return fail(-2, "istft launch failed");
@@ -747,8 +754,8 @@ static int separate_issue(srt_engine* e, const float* d_L, const float* d_R, siz
     if (rc) return rc;
     rc = forward_range(e, e->mag, (int)ntiles, e->masks, 0, e->cfg.n_stems);
     if (rc) return rc;
-    if (e->cfg.ratio_mask && (rc = srtRatioMask(e, e->masks, (int)ntiles))) return rc;
-    return srtIstft(e, (const float*)e->spec, rows, e->masks, d_out);
+    // ratio_mask: normalised across the stems inside the inverse kernel's prologue (srt_ratio_of, srt_dsp.hip) - e->masks keeps the raw sigmoid masks
+    return istft_issue(e, (const float*)e->spec, rows, e->masks, d_out, e->cfg.ratio_mask != 0);
 }
 
 int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_out)

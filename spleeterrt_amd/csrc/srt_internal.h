@@ -153,6 +153,7 @@ struct SrtIstftParams {
     const float* masks;       // [nstems][ntiles][2][T][F] or nullptr (all-ones)
     int nstems, ntiles, T, F;
     float oob[SRT_MAX_STEMS];
+    int ratio;                // 1: masks are normalised across the stems while they are applied, m_s^2 / sum_j m_j^2 (srt_config.ratio_mask; needs masks of ALL nstems)
     float* frames_out;        // [nstems][2][frames][4096] windowed time frames (temp)
     float* out;               // [nstems][2][out_len]
     size_t out_len;           // frames*1024 + 3072
