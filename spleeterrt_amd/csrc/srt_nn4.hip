@@ -1382,6 +1382,13 @@ int srt_enc_wino_covers(int Cin, int Cout, int H, int W)
 int srt_launch_enc_wino(const SrtConvParams& p, const float* U, size_t u_stem, hipStream_t s)
 {
     if (!U || p.in16 || p.out16 || p.inScale || (size_t)16 * p.srcA_tile > 0x7fffffffu || !srt_enc_wino_covers(p.Cin, p.Cout, p.H, p.W)) return 1;
+#ifdef SRT_TUNING
+    if (wino_tune("encnoact=") == 1 && p.outAct) {                           // timing ablation (wrong results): no act(BN(.)) second output for the next Winograd-form layer
+        SrtConvParams q = p; q.outAct = nullptr; q.bnScale = q.bnShift = nullptr;
+        static thread_local int depth = 0;
+        if (!depth) { ++depth; const int rc = srt_launch_enc_wino(q, U, u_stem, s); --depth; return rc; }
+    }
+#endif
     const int Ho = p.H / 2, Wo = p.W / 2;
     if (Ho >= 4 && Wo >= 32) {
         const long units = (long)((Wo + 31) / 32) * ((Ho + 3) / 4) * p.ntiles, wgs = units * (p.Cout / 32) * p.nstems;
