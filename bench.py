@@ -107,9 +107,11 @@ def layer_bytes(name, precision, act16, stems=STEMS):
 
 
 # written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first); per precision
-PMC_SUMMARIES = {"f32": [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")],
-                 "f16": [os.path.join(ROOT, "profiles", f) for f in ("r05_f16_pmc.json", "r04_f16_pmc.json", "r02_f16_pmc.json")],
-                 "f16x2": [os.path.join(ROOT, "profiles", f) for f in ("r04_f16x2_pmc.json",)]}
+# (file, stems of the profiled launch shape; every profile is of the 64-tile batch)
+PMC_SUMMARIES = {"f32": [(os.path.join(ROOT, "profiles", f), 4) for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r02_direct_pmc.json", "r01_pmc.json")],
+                 "f16": [(os.path.join(ROOT, "profiles", "r06_f16_pmc.json"), 5)] +                 # BASELINE configs[4] as written: five stems
+                        [(os.path.join(ROOT, "profiles", f), 4) for f in ("r04_f16_pmc.json", "r02_f16_pmc.json")],
+                 "f16x2": [(os.path.join(ROOT, "profiles", f), 4) for f in ("r04_f16x2_pmc.json",)]}
 N_SIMD = 1024                               # 256 CUs x 4 SIMDs: SQ_VALU_MFMA_BUSY_CYCLES is summed over them
 
 
@@ -241,13 +243,15 @@ def make_line(a, rec):
     # `profile_check` says why (a stale profile must never describe a changed kernel)
     traffic = mfma_busy = pmc_file = None
     profile_check = {"status": "no committed counter profile holds this kernel symbol", "run_avg_ms_per_launch": dom_ms}
-    for pf in PMC_SUMMARIES[prec]:
+    for pf, pf_stems in PMC_SUMMARIES[prec]:
         try:
             allpm = json.load(open(pf))
             pm = allpm.get(dom) or next((v for k, v in allpm.items() if same_kernel(k, dom)), None)
-            if pm and (a.tiles != TILES or stems != STEMS):
-                profile_check = {"status": "profiles are of the %d-tile %d-stem launch shape; this run is %d x %d" % (TILES, STEMS, a.tiles, stems), "run_avg_ms_per_launch": dom_ms}
-                break
+            if pm and (a.tiles != TILES or stems != pf_stems):
+                # (a profile of another launch shape says nothing about this run's launches: keep looking, and say so if nothing fits)
+                profile_check = {"status": "the committed profiles holding this kernel are of another launch shape (%s: %d tiles x %d stems); this run is %d x %d" % (
+                    os.path.relpath(pf, ROOT), TILES, pf_stems, a.tiles, stems), "run_avg_ms_per_launch": dom_ms}
+                continue
             if pm:
                 prof_ms = (pm.get("sq_pass_avg_ns") or pm.get("avg_ns") or 0.0) * 1e-6
                 rel = abs(prof_ms - dom_ms) / dom_ms if prof_ms else None
