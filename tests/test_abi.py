@@ -145,11 +145,12 @@ def test_bench_takes_kernel_names_from_the_engine(lib):
         m = re.search(r"(?:void )?(?:__device_stub__)?(srt_\w+(?:<[^(]*>)?)\(", ln)
         if m:
             have.add(m.group(1))
-    newest = next(p for p in bench.PMC_SUMMARIES["f32"] if os.path.exists(p))
-    named = [k for k in json.load(open(newest)) if re.match(r"srt_(enc|dec|up6|head)\w*<", k)]
-    assert named, newest
-    missing = [k for k in named if not any(bench.same_kernel(k, h) for h in have)]
-    assert not missing, "%s names kernels the library does not contain (re-run scripts/profile_gpu.sh): %r" % (newest, missing)
+    for prec in ("f32", "f16"):                             # the newest committed counter profile of each mode (f16: BASELINE configs[4]'s five-stem shape)
+        newest = next(p for p, _stems in bench.PMC_SUMMARIES[prec] if os.path.exists(p))
+        named = [k for k in json.load(open(newest)) if re.match(r"srt_(enc|dec|up6|head)\w*<", k)]
+        assert named, newest
+        missing = [k for k in named if not any(bench.same_kernel(k, h) for h in have)]
+        assert not missing, "%s names kernels the library does not contain (re-run scripts/profile_gpu.sh): %r" % (newest, missing)
 
 
 def test_bench_roofline_peaks_follow_the_precision():
