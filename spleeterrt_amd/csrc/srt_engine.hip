@@ -577,6 +577,11 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                     if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for an encoder layer");
                 } else {
                     p.c8out = c8 && i == 1;                                     // down2: planar input (down1's act copy), C8 outputs
+#ifdef SRT_TUNING
+                    // timing experiment (wrong results): down2 on the C8 kernel as if its input were C8 - what moving down1's act copy to C8 would buy
+                    static const bool d2c8 = []() { const char* v = getenv("SRT_TUNE_D2C8"); return v && v[0] == '1'; }();
+                    if (d2c8 && p.c8out) rc2 = srt_launch_enc_c8(p, e->stream); else
+#endif
                     rc2 = srt_launch_enc_f16(p, e->stream);
                 }
             }
