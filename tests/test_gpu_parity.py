@@ -956,6 +956,52 @@ def test_full_size_batch_properties(oracle, coeffs):
     eng.close()
 
 
+def test_config4_full_size_batch_properties_and_taps(oracle, coeffs):
+    """BASELINE configs[4] exactly as `bench.py --stems 5 --precision f16` launches it - 64 tiles x 5 stems of 256 x 1024, fp16-MFMA conv with the mid-network tensors
+    channel-interleaved by eight on the DMA-fed kernels of csrc/srt_nn5.hip (their grids, units per workgroup, the 4 + 1 down1 stem groups of this size).  Size-independent
+    properties on 64 DISTINCT tiles: masks finite and inside [0, 1]; a permutation of the batch permutes the masks bit for bit and a tile among silent batch mates keeps its
+    bits (tiles are independent: main.c:455-495); run to run bit-stable.  Then every tensor of three (stem, tile) instances - first / last stem, a tile in the middle and the
+    last one - against the same tile evaluated alone on the planar kernels (<= 2e-3 of the tensor's peak) and their masks against the fp32 CPU oracle (<= 2e-2)."""
+    import torch
+    import spleeterrt_amd as srt
+    T, F, S, NT = 256, 1024, 5, 64
+    eng = _engine(F=F, T=T, stem_modes=(1,) * S, variant=srt.VARIANT_VST, max_tiles=NT, precision=srt.PREC_F16)
+    for s in range(S):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, NT, T, F, seed=6006)
+    xd = torch.from_numpy(x).cuda()
+    m1 = eng.forward(xd).clone()
+    assert torch.isfinite(m1).all() and float(m1.min()) >= 0.0 and float(m1.max()) <= 1.0
+    ks = _layer_kernels(eng, xd)
+    assert ks["down3"].startswith("srt_enc_c8<") and ks["down6"].startswith("srt_enc_c8<") and ks["up1"].startswith("srt_dec_c8<") and ks["up5"].startswith("srt_dec_c8<"), ks
+    assert torch.equal(eng.forward(xd), m1)                                                      # bit-stable run to run
+    names = ["conv%d" % i for i in range(1, 7)] + ["up%d" % i for i in range(1, 7)]
+    sample = [(0, 33), (S - 1, 33), (S - 1, NT - 1)]                                             # (stem 4 = the down1 launch group of one)
+    taps = {(s, t): {n: eng.tensor(n, s, t) for n in names} for (s, t) in sample}
+    perm = torch.from_numpy(np.random.RandomState(11).permutation(NT)).cuda()
+    m2 = eng.forward(xd[perm].contiguous())
+    assert torch.equal(m2, m1[:, perm]), "masks of a permuted batch are not the permuted masks"
+    xz = xd.clone(); xz[:33] = 0.0; xz[34:] = 0.0                                                # tile 33 among silent batch mates
+    assert torch.equal(eng.forward(xz)[:, 33], m1[:, 33])
+    del m2, xz
+    for (s, t) in sample:
+        ref = oracle.forward(coeffs(s), x[t], 1, oracle.VARIANT_VST)
+        d = float(np.abs(m1[s, t].cpu().numpy() - ref).max())
+        assert d <= 2e-2, (s, t, d)
+    worst = 0.0
+    for t in sorted({t for (_, t) in sample}):
+        one = torch.from_numpy(x[t:t + 1]).cuda()
+        eng.forward(one)                                                                         # 5 instances: the planar kernels
+        for s in sorted({s for (s, tt) in sample if tt == t}):
+            for n in names:
+                a, b = taps[(s, t)][n], eng.tensor(n, s, 0)
+                err = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+                worst = max(worst, err)
+                assert err <= 2e-3, "%s stem %d tile %d: C8 batch vs planar single tile, max abs / peak %g" % (n, s, t, err)
+    print("configs[4] full size: worst tap difference between the C8 batch and the planar single tile %.3g of the tensor peak" % worst)
+    eng.close()
+
+
 # ------------------------------------------------------------------ the launch shapes the headline is timed on, per tap (VERDICT r3 #2/#3)
 SHIPPED_KERNELS = {      # bench.py's `layer_kernels` at 64 tiles x 4 stems of 256 x 1024 (profiles/r0x_bench_n1.json); template arguments may move with tuning, the families may not
     "down1": "srt_down1_stream_kernel<", "down2": "srt_enc_mfma2<", "down3": "srt_enc_wino32<", "down4": "srt_enc_wino32<", "down5": "srt_enc_wino32<", "down6": "srt_enc_wino32<",
