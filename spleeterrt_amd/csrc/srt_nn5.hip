@@ -337,9 +337,13 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
 // Transposed 5x5 stride-2 convolution as four parity classes of the output (srt_nn3.hip: srt_dec_f16); 32-pixel INPUT sub-tiles, all four classes accumulated
 // from one B fragment per input shift.  CS (up5, Cout = 16): class-stacked weights - 32 rows = 2 x-classes x 16 channels, 15 (ky, dx)
 // products per chunk, two accumulators (one per row class) - and planar fp16 stores (srt_up6_stream_kernel reads planar halves).  LW: see srt_enc_c8.
-template <int SW, int NSY, int NI, int ST, bool CS, int LW, int ABL = 0>
-__global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int tpw)
+// WPE (waves per SIMD the kernel is built for): 1 - one workgroup per CU's worth of registers.  4 - TWO workgroups per CU (<= 128 VGPRs: the epilogue constants
+// come from LDS instead of 48 registers): two independent barrier domains on a CU, so one workgroup's epilogue / DMA issue runs under the other's MFMAs - the overlap
+// the eight lock-stepped waves of one workgroup cannot give each other (ablation matrix in DESIGN.md 3.2).
+template <int SW, int NSY, int NI, int ST, bool CS, int LW, int ABL = 0, int WPE = 1>
+__global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, int tpw)
 {
+    constexpr bool EPI_LDS = WPE >= 4;
     static_assert(NSY * NI == 8 && 32 % SW == 0 && ST >= 2 && ST <= 4, "eight 32-pixel sub-tiles");
     constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
     constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : 1;
@@ -350,8 +354,9 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
     constexpr int PATCH_H = NPP * 512, WSLAB_H = NT * 512, STAGE_H = PATCH_H + WSLAB_H;
     constexpr int DPW = PPW + WPW;                             // DMA instructions per loader wave and step
     constexpr int NACC = CS ? 2 : 4;
-    __shared__ __attribute__((aligned(16))) _Float16 s_mem[ST * STAGE_H];
-    static_assert(sizeof(s_mem) <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) _Float16 s_mem[ST * STAGE_H + (EPI_LDS ? 192 : 0)];
+    static_assert(sizeof(s_mem) * (EPI_LDS ? 2 : 1) <= 160 * 1024, "LDS");
+    float* s_epi = reinterpret_cast<float*>(s_mem + ST * STAGE_H);          // EPI_LDS: bias | BN scale | BN shift of the workgroup's 32 rows
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,12 +434,31 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
     const int Wo = p.W << 1;
     const size_t ohw = (size_t)(p.H << 1) * Wo;
     float bi[16], sc[16], sf[16];
+    if constexpr (EPI_LDS) {
+        if (tid < 32) {                                        // (visible after the K loop's first barrier; first read in the first epilogue)
+            const size_t ci = stem * p.coeff_stem + (CS ? tid % 16 : m0 + tid);
+            s_epi[tid] = p.bias[ci]; s_epi[32 + tid] = p.bnScale[ci]; s_epi[64 + tid] = p.bnShift[ci];
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-        const size_t ci = stem * p.coeff_stem + (CS ? row % 16 : m0 + row);
-        bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            const size_t ci = stem * p.coeff_stem + (CS ? row % 16 : m0 + row);
+            bi[r] = p.bias[ci]; sc[r] = p.bnScale[ci]; sf[r] = p.bnShift[ci];
+        }
     }
+    auto load_epi = [&]() __attribute__((always_inline)) {    // EPI_LDS: the lane's 16 rows are four runs of four floats (rows 8 q + 4 g + 0..3)
+        if constexpr (EPI_LDS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(s_epi + 8 * q + 4 * g), s4 = *reinterpret_cast<const float4*>(s_epi + 32 + 8 * q + 4 * g),
+                             f4 = *reinterpret_cast<const float4*>(s_epi + 64 + 8 * q + 4 * g);
+                bi[4 * q] = b4.x; bi[4 * q + 1] = b4.y; bi[4 * q + 2] = b4.z; bi[4 * q + 3] = b4.w;
+                sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
+                sf[4 * q] = f4.x; sf[4 * q + 1] = f4.y; sf[4 * q + 2] = f4.z; sf[4 * q + 3] = f4.w;
+            }
+        }
+    };
     _Float16* outh = reinterpret_cast<_Float16*>(p.outAct);
     size_t obase[NR]; bool pix_ok[NR];
 #pragma unroll
@@ -455,6 +479,7 @@ __global__ void __launch_bounds__(512, 1) srt_dec_c8(const SrtConvParams p, int 
     f32x16 acc[NR][NACC];
     auto epilogue = [&]() {
         // (no early return for lanes outside the image: the lane exchanges need every lane; their stores are masked)
+        load_epi();
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             if constexpr (CS) {
@@ -589,6 +614,11 @@ static int c8_env(const char* name, int dflt)
     const char* t = getenv(name);
     return t ? atoi(t) : dflt;
 }
+// Two decoder workgroups per CU (WPE = 4) measured EQUAL to one (round 6, same box, 5 stems: step 5.006 vs 4.997 ms; up3 0.301 vs 0.322, up5 0.499 vs 0.514, the rest
+// within 2 % either way): the second barrier domain does not buy the overlap the ablation matrix prices.  Tuning library only (SRT_TUNE_C8WPE=4).
+#ifdef SRT_TUNING
+static bool c8_wpe4() { static const bool v = c8_env("SRT_TUNE_C8WPE", 1) == 4; return v; }
+#endif
 static int c8_target_wgs() { static const int v = c8_env("SPLEETERRT_C8_WGS", 1024) > 0 ? c8_env("SPLEETERRT_C8_WGS", 1024) : 1024; return v; }
 // The loader-wave form (LW = 1) measured SLOWER on every layer but down5 / down6 (round 6, same box: 5-stem step 5.26 vs 5.09 ms; up4 0.434 vs 0.385): with one
 // computing wave per SIMD the MFMA stream loses more to its own LDS-read latency than the other waves lose to the DMA issue.  It is compiled into the tuning
@@ -643,12 +673,26 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
 #define C8_DEC_CASE(A) if (c8_abl() == A) { if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0, A>), grid, dim3(512), 0, s, p, tpw); else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
         C8_ABL_CASES(C8_DEC_CASE)
 #endif
+#ifdef SRT_TUNING
+        if (c8_wpe4()) {
+            if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0, 0, 4>), grid, dim3(512), 0, s, p, tpw);
+            else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 2, false, 0, 0, 4>), grid, dim3(512), 0, s, p, tpw);
+            return srt_launch_status();
+        }
+#endif
         if (cs) C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0>), grid, dim3(512), 0, s, p, tpw));
         else C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
         const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
+#ifdef SRT_TUNING
+        if (c8_wpe4()) {
+            if (cs) SRT_LAUNCH((srt_dec_c8<16, 2, 4, 2, true, 0, 0, 4>), grid, dim3(512), 0, s, p, tpw);
+            else SRT_LAUNCH((srt_dec_c8<16, 2, 4, 2, false, 0, 0, 4>), grid, dim3(512), 0, s, p, tpw);
+            return srt_launch_status();
+        }
+#endif
         if (cs) C8_LW(SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, true, 0>), grid, dim3(512), 0, s, p, tpw));
         else C8_LW(SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<16, 2, 4, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     }
