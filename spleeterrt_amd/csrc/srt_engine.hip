@@ -116,6 +116,7 @@ struct srt_engine {
     float* act16buf[5];                                // fp16-storage mode only: act(bn(raw_i)) as halves, written by the producer
     bool act16;                                        // raw[0..5] and up[0..4] hold IEEE halves (precision F16 on a supported geometry)
     uint16_t* wpack16cs_u5;                            // act16 only: up5's class-stacked fp16 weights [n_stems][4][15][2][32][8] (srt_nn5.hip)
+    SrtConvParams up6_params; int up6_s0; unsigned up6_stale;          // the last forward ran up6 + head in one pass (no up6 plane stored): srtCopyTensor("up6") re-launches up6 alone from these
     bool last_c8;                                      // the last forward stored raw2..6 / act2..5 / up1..4 channel-interleaved by eight (srt_nn5.hip): srtCopyTensor's view
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
@@ -211,7 +212,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
     memset(e->wino_e, 0, sizeof e->wino_e); memset(e->wino_e_stem, 0, sizeof e->wino_e_stem); memset(e->act32, 0, sizeof e->act32);
-    e->wpack16cs_u5 = nullptr; e->last_c8 = false;
+    e->wpack16cs_u5 = nullptr; e->last_c8 = false; e->up6_stale = 0; e->up6_s0 = 0;
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -590,6 +591,13 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             if (rc2 < 0) return fail(-2, "encoder launch failed");
             if (rc2 == 1 && srt_launch_enc(p, e->cfg.impl, e->stream)) return fail(-2, "encoder launch failed");
         }
+        SrtHeadParams head; memset(&head, 0, sizeof head);                     // head (spleeter.c:295-300)
+        head.H = T; head.W = F; head.ntiles = ntiles; head.nstems = ns;
+        head.src = e->up[5] + (size_t)s0 * ntiles * e->up_tile[5]; head.src_stem = (size_t)ntiles * e->up_tile[5]; head.src_tile = e->up_tile[5];
+        head.w = cbase + e->lo.head_w; head.bias = cbase + e->lo.head_b; head.coeff_stem = SRT_COEFF_STRIDE;
+        head.out = d_masks + (size_t)s0 * ntiles * 2 * HW; head.out_stem = (size_t)ntiles * 2 * HW; head.out_tile = 2 * HW;
+        head.variant = e->cfg.variant;
+        bool head_done = false;
         for (int i = 0; i < 6; ++i) {                                           // decoder (spleeter.c:239-294)
             const LayerOff& L = e->lo.up[i];
             SrtConvParams p; memset(&p, 0, sizeof p);
@@ -624,21 +632,23 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                     if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for a decoder layer");
                 } else rc2 = srt_launch_dec_f16(p, e->stream);
             }
+            if (i == 5) {                                                       // up6 + head in one pass where covered (srt_up6_head_kernel); the plane is then not stored
+                const unsigned bits = ((1u << ns) - 1u) << s0;
+                e->up6_stale &= ~bits;
+                if (e->cfg.impl == SRT_IMPL_MFMA && !e->graph_mode) {              // (graph replays would not maintain up6_stale; graphs are for launches far below this form's threshold)
+                    rc2 = srt_launch_up6_head(p, head, e->stream);
+                    if (rc2 == 0) { head_done = true; e->up6_stale |= bits; e->up6_params = p; e->up6_s0 = s0; }
+                }
+            }
             if (e->act16 && i < 5 && rc2 == 1) return fail(-4, "internal: fp16 activation storage but no fp16 kernel for a decoder layer");
             if (rc2 == 1 && e->wino_u[i] && (!few || srt_wino_force())) rc2 = srt_launch_dec_wino(p, e->wino_u[i] + (size_t)s0 * e->wino_u_stem[i], e->wino_u_stem[i], e->stream);
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA) rc2 = srt_launch_dec2(p, e->stream);
             if (rc2 < 0) return fail(-2, "decoder launch failed");
             if (rc2 == 1 && srt_launch_dec(p, e->cfg.impl, e->stream)) return fail(-2, "decoder launch failed");
         }
-        {                                                                       // head (spleeter.c:295-300)
-            SrtHeadParams h; memset(&h, 0, sizeof h);
-            h.H = T; h.W = F; h.ntiles = ntiles; h.nstems = ns;
-            h.src = e->up[5] + (size_t)s0 * ntiles * e->up_tile[5]; h.src_stem = (size_t)ntiles * e->up_tile[5]; h.src_tile = e->up_tile[5];
-            h.w = cbase + e->lo.head_w; h.bias = cbase + e->lo.head_b; h.coeff_stem = SRT_COEFF_STRIDE;
-            h.out = d_masks + (size_t)s0 * ntiles * 2 * HW; h.out_stem = (size_t)ntiles * 2 * HW; h.out_tile = 2 * HW;
-            h.variant = e->cfg.variant;
+        if (!head_done) {
             TimerScope ts(e, "up7");
-            if (srt_launch_head(h, e->stream)) return fail(-2, "head launch failed");
+            if (srt_launch_head(head, e->stream)) return fail(-2, "head launch failed");
         }
     }
     return 0;
@@ -1070,6 +1080,10 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     else return fail(-1, "srtCopyTensor: unknown tensor %s", name);
     if (per > max_floats) return fail(-1, "srtCopyTensor: destination too small");
     // instance stride = ntiles of the last srtForward call
+    if (name[0] == 'u' && idx == 5 && ((e->up6_stale >> stem) & 1u)) {       // the fused launch kept the plane in LDS: materialise the tap with the plain up6 kernel
+        if (stem < e->up6_s0 || stem >= e->up6_s0 + e->up6_params.nstems) return fail(-1, "srtCopyTensor: up6 of this stem was not stored by the fused up6 + head launch of an earlier stem range");
+        if (srt_launch_dec(e->up6_params, e->cfg.impl, e->stream)) return fail(-2, "up6 launch failed");
+    }
     const bool halves = e->act16 && !(name[0] == 'u' && idx == 5);           // up6 (the head's input) is always fp32
     const float* src = halves ? eoff(e, const_cast<float*>(base), ((size_t)stem * e->last_ntiles + tile) * per) : base + ((size_t)stem * e->last_ntiles + tile) * per;
     float* tmp = nullptr;

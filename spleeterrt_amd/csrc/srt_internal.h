@@ -99,6 +99,7 @@ struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sig
 int  srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s);
 int  srt_launch_head(const SrtHeadParams& p, hipStream_t s);
+int  srt_launch_up6_head(const SrtConvParams& p, const SrtHeadParams& h, hipStream_t s);   // both layers in one pass; 1: not covered / switched off
 int  srt_launch_bn_act(const float* raw, int raw16, float* out, const float* scale, const float* shift, int C, size_t hw, int kind, int variant, hipStream_t s);
 int  srt_launch_half_to_float(const void* src, float* dst, size_t n, hipStream_t s);
 int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);

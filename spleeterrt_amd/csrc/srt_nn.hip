@@ -945,6 +945,232 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
     }
 }
 
+// ------------------------------------------------------------------------------------------- up6 + head in one pass down a tile column
+// The reference runs up6 and the head in place over one buffer (spleeter.c:285-300); srt_up6_stream_kernel + srt_head_rows_kernel write the 1-channel plane
+// (1 MiB per instance) and read it back.  Here the column workgroup of the streamed up6 keeps its output rows in an LDS ring and emits the two mask planes itself:
+//   * the head's taps reach three output columns either side of the column, i.e. the up6 outputs of TWO more input pixels per side: the tap planes are computed for
+//     TW + 6 patch columns instead of TW + 2 - columns the 16-byte DMA segments already bring (tx0 - EPP .. tx0 + TW + EPP - 1) and the fifth 32-pixel MFMA group
+//     already has room for (2 x 70 = 140 <= 160 pixels), so the halo costs no load and no MFMA, only a second gather pass of four lanes;
+//   * the gather waves store their quads into a ring of 16 up6 output rows (136 columns) instead of global memory, and each of the four DMA / MFMA waves then evaluates
+//     the head for 64 columns of two same-parity output rows (they share three of their five input rows: 20 LDS reads for 4 mask values), lagging the gather by one
+//     interval: interval i gathers rows 4i-6..4i-3 and emits head rows 4i-13..4i-10 from rows 4i-16..4i-7 - fourteen live rows, one barrier per interval as before.
+// Rows / columns outside the image are never read from the ring: the head predicates on coordinates (and, like srt_head_rows_kernel, still issues the FMA with a zero).
+// Same MFMA chains, same gather order, same FMA chain per mask value ((ky, kx) ascending on both channels at once) as the two kernels it replaces: bit-identical masks.
+// LDS: fp32 88.8 KB (ONE workgroup per CU), fp16 storage 72.4 KB (two).  The up6 plane is not written; srtCopyTensor("up6") re-runs the plain up6 launch on demand.
+// MEASURED SLOWER than the two kernels in both modes (profiles/r06_fuse_pmc.json) and therefore OFF unless SPLEETERRT_FUSE_HEAD=1: the head's 181 M
+// VALU instructions are free in a kernel of its own (bandwidth-bound, idle vector ALU) and are not inside a column workgroup whose interval is a chain of dependent
+// LDS round trips behind one barrier; and with the intervals twice as long the columns of an XCD drift apart, so the halo lines neighbours share stop hitting in L2
+// (fp16 storage: 2.23 GB fetched against 1.45).
+template <int TW, int CR, bool H16, bool LUT>
+__global__ void __launch_bounds__(512, H16 ? 4 : 2) srt_up6_head_kernel(const SrtConvParams p, const SrtHeadParams hp)
+{
+    constexpr int CIN = 32, CAH = 16, HALO = 2;
+    constexpr int EPP = H16 ? 8 : 4, ESZ = H16 ? 2 : 4, LEAD = EPP - 1 - HALO;   // patch column of pixel tx0 - 1 - HALO = tap-plane column 0
+    constexpr int PW = TW + 2 + 2 * HALO, SEG = TW / EPP + 2, PROW = SEG * EPP;
+    constexpr int CHF4 = CR * SEG, NF4 = CIN * CHF4, NPIECE = NF4 / 64, NWAVE = 8, NDW = 4, PPW = (NPIECE + NDW - 1) / NDW;
+    static_assert(NF4 % 64 == 0 && (CAH * CHF4) % 64 == 0, "a DMA piece (64 lanes x 16 B) must not straddle the two source tensors");
+    static_assert(TW == 64 && CR == 2 && 2 * CR == NWAVE - NDW, "gather: a wave per (row of the chunk, output row parity); head: a wave per (64-column half, row parity)");
+    static_assert(LEAD >= 0 && LEAD + PW <= PROW, "the halo columns lie inside the DMA'd row");
+    constexpr int PBUF = CIN * CR * PROW, PBUF_F = PBUF * ESZ / 4;
+    constexpr int RR = 2 * CR + 2, RWP = 72;
+    static_assert(RWP >= PW, "ring pitch");
+    constexpr int NPIX = CR * PW, NG = (NPIX + 31) / 32;
+    static_assert(NG <= NWAVE, "one pixel group per wave");
+    constexpr int OR = 16, OP = 2 * (TW + 2 * HALO);                         // ring of up6 output rows: slot = row & 15; column 0 = output column 2 (tx0 - HALO)
+    __shared__ __attribute__((aligned(16))) float s_all[2 * PBUF_F + RR * 25 * RWP + OR * OP];
+    float* s_p = s_all;
+    float* s_r = s_all + 2 * PBUF_F;
+    float* s_o = s_r + RR * 25 * RWP;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesX = (p.W + TW - 1) / TW;
+    const int pos = srt_xcd_order(tilesX * p.nstems * p.ntiles), tx0 = (pos % tilesX) * TW, inst = pos / tilesX;
+    const int stem = inst / p.ntiles, tile = inst % p.ntiles;
+    const SrtAct actp = srt_act_params(srt_act_kind(p, stem), p.variant);
+    const size_t hw = (size_t)p.H * p.W;
+    const float* w = p.wraw + stem * p.coeff_stem;                            // [Cin][1][25]
+    float a[H16 ? 1 : CIN / 2];
+    srt_h8 a16[H16 ? 2 : 1];
+    if constexpr (H16) {                                                      // (every wave may run an MFMA group: group NDW goes round the gather waves)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = w[(kg * 16 + half * 8 + q) * 25 + min(l31, 24)];
+                a16[kg][q] = (_Float16)(l31 < 25 ? v : 0.0f);
+            }
+    } else {
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) {
+            const float v = w[(2 * cp + half) * 25 + min(l31, 24)];
+            a[cp] = l31 < 25 ? v : 0.0f;
+        }
+    }
+    constexpr unsigned OOR = 0x80000000u;
+    unsigned c0[PPW]; int prow[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = min(wave + NDW * q, NPIECE - 1), e = piece * 64 + lane;
+        const int j = e % SEG, row = (e / SEG) % CR, chl = (e / CHF4) % CAH, gx = tx0 - EPP + EPP * j;
+        prow[q] = row;
+        c0[q] = (gx >= 0 && gx + EPP - 1 < p.W) ? (unsigned)ESZ * (unsigned)((size_t)chl * hw + (size_t)row * p.W + gx) : OOR;
+    }
+    const size_t ba_ = (size_t)p.srcA + (size_t)ESZ * (stem * p.srcA_stem + tile * p.srcA_tile), bb_ = (size_t)p.srcB + (size_t)ESZ * (stem * p.srcB_stem + tile * p.srcB_tile);
+    srt_i32x4 rsA, rsB;
+    rsA.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba_); rsA.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba_ >> 32) & 0xffffu));
+    rsB.x = __builtin_amdgcn_readfirstlane((int)(unsigned)bb_); rsB.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(bb_ >> 32) & 0xffffu));
+    rsA.z = rsB.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)ESZ * CAH * hw); rsA.w = rsB.w = 0x00020000;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_all;
+    auto dma_chunk = [&](int i) {
+        const unsigned adv = (unsigned)ESZ * (unsigned)(i * CR * p.W), base = lds0 + (unsigned)((i & 1) * PBUF * ESZ);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int piece = min(wave + NDW * q, NPIECE - 1);
+            const unsigned voff = (c0[q] != OOR && i * CR + prow[q] < p.H) ? c0[q] + adv : OOR;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(piece * 1024));
+            if (piece < NPIECE / 2) asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsA), "s"(dst) : "memory");
+            else asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsB), "s"(dst) : "memory");
+        }
+    };
+    for (int e = tid; e < RR * 25 * RWP; e += 64 * NWAVE) s_r[e] = 0.0f;
+    const int nchunks = (p.H + CR - 1) / CR + 1;
+    if (wave < NDW) dma_chunk(0);
+    const float bi = p.bias[stem * p.coeff_stem], sc = p.bnScale[stem * p.coeff_stem], sf = p.bnShift[stem * p.coeff_stem];
+    // ---- head constants (gather waves): (channel 0, channel 1) weight of each tap
+    const int Ho = p.H << 1, Wo = p.W << 1;
+    const size_t ohw = (size_t)Ho * Wo;
+    srt_v2f wk[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { wk[t].x = hp.w[stem * hp.coeff_stem + t]; wk[t].y = hp.w[stem * hp.coeff_stem + 16 + t]; }
+    const float hb0 = hp.bias[stem * hp.coeff_stem], hb1 = hp.bias[stem * hp.coeff_stem + 1];
+    float* y = hp.out + stem * hp.out_stem + tile * hp.out_tile;
+    int slot0 = 0;
+    for (int i = 0; i <= nchunks + 2; ++i) {                                 // two more intervals than the plain kernel: the head lags the gather
+        if (wave < NDW) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (wave < NDW && i + 1 < nchunks) dma_chunk(i + 1);
+        const int grp = wave < NDW ? wave : NDW + ((wave - i) & (NWAVE - NDW - 1));
+        if (i < nchunks && grp < NG) {
+            const int pix = min(grp * 32 + l31, NPIX - 1), row = pix / PW, col = pix % PW;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if constexpr (H16) {
+                const _Float16* bsrc = reinterpret_cast<const _Float16*>(s_p) + (i & 1) * PBUF + (half * 8 * CR + row) * PROW + col + LEAD;
+                srt_h8 b16[2];
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) b16[kg][q] = bsrc[(kg * 16 + q) * CR * PROW];
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[kg], b16[kg], acc, 0, 0, 0);
+            } else {
+                const float* bsrc = s_p + (i & 1) * PBUF + (half * CR + row) * PROW + col + LEAD;
+                float b[CIN / 2];
+#pragma unroll
+                for (int cp = 0; cp < CIN / 2; ++cp) b[cp] = bsrc[cp * 2 * CR * PROW];
+#pragma unroll
+                for (int cp = 0; cp < CIN / 2; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b[cp], acc, 0, 0, 0);
+            }
+            int slot = slot0 + row; slot = slot >= RR ? slot - RR : slot;
+            if (grp * 32 + l31 < NPIX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (tap < 25) s_r[(slot * 25 + tap) * RWP + col] = acc[r];
+                }
+            }
+        }
+        const int gw = wave - NDW;
+        if (gw >= 0) {                                                        // wave-uniform
+            // ---- gather: input row g = CR (i - 1) - 1 + a0, output row 2 g + py, pixel tx0 - HALO + q -> ring of up6 output rows
+            auto gather = [&](auto pyc, int a0, int q) __attribute__((always_inline)) {
+                constexpr int PY = decltype(pyc)::value;
+                const int g = CR * (i - 1) - 1 + a0;
+                int sm = slot0 - CR - 2 + a0; sm = sm < 0 ? sm + RR : sm;
+                const int s1 = sm + 1 >= RR ? sm + 1 - RR : sm + 1, s2 = s1 + 1 >= RR ? s1 + 1 - RR : s1 + 1;
+                const float* r0 = s_r + sm * 25 * RWP + q + 1;
+                const float* r1 = s_r + s1 * 25 * RWP + q + 1;
+                const float* r2 = s_r + s2 * 25 * RWP + q + 1;
+                float o[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int tap = 0; tap < 25; ++tap) {                          // ascending (ky, kx): the reference's col2im order
+                    const int ky = tap / 5, kx = tap % 5;
+                    if (((ky + 1) & 1) != PY) continue;
+                    const int px = (kx + 1) & 1, dy = (PY + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+                    o[px] += (dy < 0 ? r0 : dy == 0 ? r1 : r2)[tap * RWP + dx];
+                }
+                float2 v;
+                v.x = srt_dec_epilogue(o[0], bi, sc, sf, actp);
+                v.y = srt_dec_epilogue(o[1], bi, sc, sf, actp);
+                *reinterpret_cast<float2*>(s_o + ((2 * g + PY) & (OR - 1)) * OP + 2 * q) = v;
+            };
+            {                                                                 // the wave's (a0, py), pixels tx0 - HALO + lane
+                const int a0 = gw % CR, py = gw / CR, g = CR * (i - 1) - 1 + a0, gb = tx0 - HALO + lane;
+                if (g >= 0 && g < p.H && gb >= 0 && gb < p.W) {
+                    if (py) gather(std::integral_constant<int, 1>{}, a0, lane); else gather(std::integral_constant<int, 0>{}, a0, lane);
+                }
+            }
+            if (gw == ((i + 2) & (NWAVE - NDW - 1))) {                        // the last 2 HALO pixels of all four (a0, py): sixteen lanes of ONE wave (not the one that runs MFMA group NDW this interval)
+                const int q = TW + (lane & 3), a0 = (lane >> 3) & 1, py = (lane >> 2) & 1, g = CR * (i - 1) - 1 + a0, gb = tx0 - HALO + q;
+                const bool ok = lane < 16 && g >= 0 && g < p.H && gb >= 0 && gb < p.W;
+                if (ok && py == 0) gather(std::integral_constant<int, 0>{}, a0, q);
+                if (ok && py == 1) gather(std::integral_constant<int, 1>{}, a0, q);
+            }
+        } else {
+            // ---- head (the DMA / MFMA waves: two instructions' worth of MFMA work in the fp16 form): output rows h, h + 2 (h = 4 i - 13 + parity) of columns
+            //      2 tx0 + 64 hh + lane, from ring rows h - 3, h - 1, .. h + 5 (written in earlier intervals)
+            const int hh = wave & 1, h = 4 * i - 13 + (wave >> 1);
+            const int wcol = 2 * tx0 + 64 * hh + lane;
+            if (h + 2 >= 0 && h < Ho && wcol < Wo) {
+                srt_v2f ac[2];
+                ac[0].x = ac[0].y = ac[1].x = ac[1].y = 0.0f;
+                const float* oc = s_o + 64 * hh + lane + 2 * HALO - 3;        // ring column of output column wcol - 3
+                const bool inside = h - 3 >= 0 && h + 5 < Ho && 2 * tx0 + 64 * hh - 3 >= 0 && 2 * tx0 + 64 * hh + 66 < Wo;   // wave-uniform: no tap of the wave leaves the image
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const int r = h - 3 + 2 * m;
+                    const bool rok = r >= 0 && r < Ho;
+                    const float* orow = oc + (r & (OR - 1)) * OP;
+                    float win[4];
+                    if (inside) {
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) win[kx] = orow[2 * kx];
+                    } else {
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const int c = wcol - 3 + 2 * kx;
+                            const float v = orow[2 * kx];
+                            win[kx] = (rok && c >= 0 && c < Wo) ? v : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ky = m - j;
+                        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const srt_v2f vv = { win[kx], win[kx] };
+                            ac[j] = __builtin_elementwise_fma(wk[ky * 4 + kx], vv, ac[j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int hr = h + 2 * j;
+                    if (hr < 0 || hr >= Ho) continue;
+                    float m0, m1;
+                    if (LUT) { m0 = srt_sigmoid(ac[j].x + hb0, 0); m1 = srt_sigmoid(ac[j].y + hb1, 0); }
+                    else { m0 = srt_sigmoid_fast(ac[j].x + hb0); m1 = srt_sigmoid_fast(ac[j].y + hb1); }
+                    __builtin_nontemporal_store(m0, y + (size_t)hr * Wo + wcol);     // (the masks are next read by the inverse transform, a launch later: keep them out of the L2 the column's neighbours share their halo lines through)
+                    __builtin_nontemporal_store(m1, y + ohw + (size_t)hr * Wo + wcol);
+                }
+            }
+        }
+        slot0 += CR; slot0 = slot0 >= RR ? slot0 - RR : slot0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- dispatch
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC>
 static int launch_enc_cfg(const SrtConvParams& p, hipStream_t s)
@@ -988,6 +1214,9 @@ int srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s)
 
 #ifndef SRT_UP6_STREAM_DEFAULT
 #define SRT_UP6_STREAM_DEFAULT 1
+#endif
+#ifndef SRT_FUSE_HEAD_DEFAULT
+#define SRT_FUSE_HEAD_DEFAULT(in16) 0       // measured slower in both storage modes (round 6: fp32 1.24 vs 0.58 + 0.16 ms, fp16 storage at five stems 0.71 vs 0.39 + 0.21)
 #endif
 int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
@@ -1037,6 +1266,22 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
     if (p.Cout <= 32) return launch_dec_cfg<32, 1, 32, 2, 4, 1, 4>(p, s);                    // up4/up5: 4 rows x 64 cols
     if (p.W >= 32) return launch_dec_cfg<64, 2, 32, 1, 4, 1, 4>(p, s);                       // up2/up3: 4 rows x 32 cols
     return launch_dec_cfg<64, 2, 16, 1, 2, 2, 4>(p, s);                                      // up1: 2 instances of 4x16
+}
+
+// up6 + head in one pass (srt_up6_head_kernel).  Returns 1 when the launch is not covered or the form is switched off: the caller then launches the two layers
+// separately.  SPLEETERRT_FUSE_HEAD: 0 never, 1 whenever covered, unset: where it measured faster.
+int srt_launch_up6_head(const SrtConvParams& p, const SrtHeadParams& h, hipStream_t s)
+{
+    const char* fv = getenv("SPLEETERRT_FUSE_HEAD");                          // (read per launch: the parity tests switch it inside one process)
+    const int mode = fv && fv[0] ? atoi(fv) : -1;
+    if (mode == 0 || (mode < 0 && !SRT_FUSE_HEAD_DEFAULT(p.in16))) return 1;
+    if (p.Cout != 1 || p.Cin != 32 || p.CA != 16 || p.out16 || !p.srcA || !p.srcB || (p.H & 1) || p.W % (p.in16 ? 8 : 4)) return 1;
+    if ((size_t)64 * p.H * p.W >= 0x7fffffffu || h.H != 2 * p.H || h.W != 2 * p.W || h.ntiles != p.ntiles || h.nstems != p.nstems) return 1;
+    const long cols = (long)((p.W + 63) / 64) * p.nstems * p.ntiles;
+    if (cols < 512) return 1;
+    if (p.in16) { if (h.variant == 0) SRT_LAUNCH((srt_up6_head_kernel<64, 2, true, true>), dim3((unsigned)cols), dim3(512), 0, s, p, h); else SRT_LAUNCH((srt_up6_head_kernel<64, 2, true, false>), dim3((unsigned)cols), dim3(512), 0, s, p, h); }
+    else { if (h.variant == 0) SRT_LAUNCH((srt_up6_head_kernel<64, 2, false, true>), dim3((unsigned)cols), dim3(512), 0, s, p, h); else SRT_LAUNCH((srt_up6_head_kernel<64, 2, false, false>), dim3((unsigned)cols), dim3(512), 0, s, p, h); }
+    return srt_launch_status();
 }
 
 int srt_launch_head(const SrtHeadParams& p, hipStream_t s)

@@ -193,6 +193,63 @@ def test_up6_streamed_form(oracle, coeffs, T, F, ntiles, stems):
     print("up6 streamed %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("T,F,ntiles,stems,precision,variant", [
+    (64, 512, 33, 4, "f32", "vst"),       # four full 64-pixel columns per instance, 132 instances; exact sigmoid
+    (64, 576, 29, 4, "f32", "lut"),       # W = 288: a 32-pixel last column (the right image edge inside the halo the head needs); table sigmoid
+    (128, 256, 65, 4, "f16", "vst"),      # fp16 activation storage (8-pixel DMA pieces; F % 256 == 0, so every column is full), two columns per instance, 34 intervals
+    (256, 1024, 16, 4, "f16", "lut"),     # the bench tile geometry (8 columns x 131 intervals) on fp16 storage
+    (256, 1024, 16, 5, "f32", "vst"),     # ... and on fp32 tensors, five stems (one workgroup per CU: 88.8 KB of LDS)
+])
+def test_up6_and_head_in_one_pass(oracle, coeffs, T, F, ntiles, stems, precision, variant):
+    """srt_up6_head_kernel (csrc/srt_nn.hip) - the streamed up6 keeps its output rows in an LDS ring and emits the two mask planes itself, so the
+    1-channel plane is neither written nor re-read.  Same MFMA chains, gather order and head FMA chain as srt_up6_stream_kernel + srt_head_rows_kernel:
+    the masks of the whole batch must be BIT-IDENTICAL to the two-kernel form (SPLEETERRT_FUSE_HEAD=0), the engine must name the fused kernel for up6 and
+    launch no up7, the up6 tap (re-materialised on demand by srtCopyTensor) must equal the two-kernel form's plane bit for bit, and the masks hold the
+    mode's tolerance against the fp32 oracle on the first, an interior and the last tile of the first and the last stem."""
+    import os
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    var = srt.VARIANT_VST if variant == "vst" else srt.VARIANT_EXE
+    ovar = oracle.VARIANT_VST if variant == "vst" else oracle.VARIANT_EXE
+    kw = dict(precision=srt.PREC_F16) if precision == "f16" else dict(impl=srt.IMPL_MFMA)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=var, max_tiles=ntiles, **kw)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=7700 + T + F)
+    xd = torch.from_numpy(x).cuda()
+    old = os.environ.get("SPLEETERRT_FUSE_HEAD")
+    try:
+        os.environ["SPLEETERRT_FUSE_HEAD"] = "0"
+        two = eng.forward(xd).cpu().numpy().copy()
+        k2 = _layer_kernels(eng, xd)
+        assert k2["up6"].startswith("srt_up6_stream_kernel<") and k2["up7"].startswith("srt_head_rows_kernel<"), (k2["up6"], k2.get("up7"))
+        picks = [(s, t) for s in (0, stems - 1) for t in sorted({0, ntiles // 2, ntiles - 1})]
+        planes = {st: eng.tensor("up6", *st) for st in picks}
+        os.environ["SPLEETERRT_FUSE_HEAD"] = "1"
+        eng.forward(xd.clone())                                  # (another batch in between would be better still: the plane buffer keeps the two-kernel run's values)
+        one = eng.forward(xd).cpu().numpy()
+        k1 = _layer_kernels(eng, xd)
+        assert k1["up6"].startswith("srt_up6_head_kernel<64, 2, %s" % ("true" if precision == "f16" else "false")), k1["up6"]
+        assert "up7" not in k1, k1
+        assert np.array_equal(one, two), "masks differ: %d values, worst %g" % (int((one != two).sum()), float(np.abs(one - two).max()))
+        for st in picks:
+            assert np.array_equal(eng.tensor("up6", *st), planes[st]), st
+    finally:
+        if old is None:
+            os.environ.pop("SPLEETERRT_FUSE_HEAD", None)
+        else:
+            os.environ["SPLEETERRT_FUSE_HEAD"] = old
+    tol = 2e-2 if precision == "f16" else (MASK_TOL_EXACT if variant == "vst" else MASK_TOL_LUT)
+    worst = 0.0
+    for s, t in picks:
+        ref = oracle.forward(coeffs(s), x[t], modes[s], ovar)
+        worst = max(worst, float(np.abs(one[s, t] - ref).max()))
+        assert worst <= tol, (s, t, worst)
+    eng.close()
+    print("up6 + head in one pass %dx%d x%d x%d %s %s: masks bit-identical to the two-kernel form, worst mask error vs the oracle %.3g" % (T, F, ntiles, stems, precision, variant, worst))
+
+
 def test_up6_streamed_form_fp16_storage(oracle, coeffs):
     """The streamed up6 on fp16 activation tensors (srt_up6_stream_kernel<.., H16>, round 4: 8-pixel DMA pieces, the tiled fp16 kernel's two
     v_mfma_f32_32x32x16_f16 per 32 pixels): named by the engine at 33 tiles x 4 stems of 64 x 512, its output plane bit-identical to the tiled kernel's
