@@ -62,6 +62,7 @@ struct SrtConvParams {
                           // up5:   [Cin][15][32] per stem, rows = px*16+co, 15 = (ky, dx) pairs (two x-parity classes per tile)
     size_t wpack2_stem;
     int CP2, stack;
+    int rowsplit;         // srt_down1_stream_kernel<.., NW = 2>: runs of intervals a column is cut into (one workgroup each); 0 / 1: whole columns
     // fp16-MFMA variant (srt_nn3.hip): [Cin/16][25][2][CP][8] IEEE halves (k-group of 8 channels innermost)
     const uint16_t* wpack16; size_t wpack16_stem;
     int nsplit;           // 1: activations rounded to fp16; 2: activations split hi+lo (two MFMAs per tap, ~fp32 products)

@@ -458,51 +458,70 @@ __global__ void __launch_bounds__(DUAL ? 512 : 256, ABL == 30 ? 3 : 2) srt_enc_m
 #define SRT_D1S_PITCH 144
 typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
 // H16 (fp16 activation storage, srt_config.precision F16): conv + bias AND act(BN(.)) leave as halves, two 8-byte stores per channel row (see srt_enc_mfma2, twoOut)
-template <int ABL = 0, bool H16 = false>                                        // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
-__global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvParams p)
+// NW = 2 (round 6): launches of ONE M tile (one or two stems - e.g. the fifth stem of BASELINE configs[4], which used to fall back to the tiled kernel at 0.24 ms, as
+// much as the four stacked stems' streamed launch costs for its MFMAs alone).  The M tile mt = 1 has nothing to compute there, so the workgroup is the two mt = 0 waves
+// (half the MFMAs per interval), four workgroups per CU instead of two, and - to have that many - a column is cut into p.rowsplit runs of intervals, each started from
+// the three chunks around its first row.  Same chain per output as NW = 4: bit-identical.
+template <int ABL = 0, bool H16 = false, int NW = 4>                            // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
+__global__ void __launch_bounds__(NW * 64, 2) srt_down1_stream_kernel(const SrtConvParams p)
 {
-    constexpr int PITCH = SRT_D1S_PITCH, RING = 32, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64;      // 576 float4 = 9 pieces per chunk
+    static_assert(NW == 4 || NW == 2, "four waves (two M tiles x two row pairs) or two (one M tile)");
+    constexpr int PITCH = SRT_D1S_PITCH, RING = 32, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64, PPW = (NPIECE + NW - 1) / NW;      // 576 float4 = 9 pieces per chunk
     static_assert(CH_F4 % 64 == 0 && NPIECE == 9, "a chunk is whole DMA pieces");
     __shared__ __attribute__((aligned(16))) float s_ring[RING * 2 * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = wave & 1, reg = wave >> 1;
+    const int mt = NW == 4 ? (wave & 1) : 0, reg = NW == 4 ? (wave >> 1) : wave;
     const int Ho = p.H >> 1, Wo = p.W >> 1, strips = Wo / 64;
-    const int pos = srt_xcd_order(strips * p.ntiles), ox0 = (pos % strips) * 64, tile = pos / strips;
+    const int nparts = NW == 4 ? 1 : max(p.rowsplit, 1);
+    const int pos = srt_xcd_order(strips * p.ntiles * nparts), ox0 = (pos % strips) * 64, part = (pos / strips) % nparts, tile = pos / (strips * nparts);
     const int mlimit = p.stack * 16;
     // A operands: w[stacked row][channel = half][tap] from the stem-stacked pack [2][25][CP2]; rows past the last stem are zero in the pack
     float a[25];
 #pragma unroll
     for (int tap = 0; tap < 25; ++tap) a[tap] = p.wpack2[(size_t)(half * 25 + tap) * p.CP2 + mt * 32 + l31];
     // output rows of this lane's 16 accumulator registers: stacked row m = 32 mt + (r & 3) + 8 (r >> 2) + 4 half -> (stem, channel)
-    float bi[16]; unsigned ob[16];
-    float sc2[H16 ? 16 : 1], sf2[H16 ? 16 : 1];
+    constexpr bool EPI_LDS = NW == 2 && H16;                                    // the 48 epilogue constants from LDS: with five DMA offsets instead of three they no longer fit beside 64 accumulators
+    __shared__ __attribute__((aligned(16))) float s_epi[EPI_LDS ? 96 : 4];      // bias | BN scale | BN shift of the M tile's 32 rows
+    float bi[EPI_LDS ? 1 : 16]; unsigned ob[NW == 4 ? 16 : 1];                   // (NW = 2: the row offsets are wave-uniform arithmetic on top of a per-lane base)
+    float sc2[H16 && !EPI_LDS ? 16 : 1], sf2[H16 && !EPI_LDS ? 16 : 1];
     const size_t ohw = (size_t)Ho * Wo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, mlimit - 1), st = m >> 4, co = m & 15;
-        bi[r] = p.bias[st * p.coeff_stem + co];
-        if constexpr (H16) { sc2[r] = p.bnScale[st * p.coeff_stem + co]; sf2[r] = p.bnShift[st * p.coeff_stem + co]; }
-        ob[r] = (unsigned)(st * p.out_stem + (size_t)co * ohw);                 // (the launcher checks that the output tensor has fewer than 2^32 elements)
+        if constexpr (!EPI_LDS) {
+            bi[r] = p.bias[st * p.coeff_stem + co];
+            if constexpr (H16) { sc2[r] = p.bnScale[st * p.coeff_stem + co]; sf2[r] = p.bnShift[st * p.coeff_stem + co]; }
+        }
+        if constexpr (NW == 4) ob[r] = (unsigned)(st * p.out_stem + (size_t)co * ohw);   // (the launcher checks that the output tensor has fewer than 2^32 elements)
     }
+    if constexpr (EPI_LDS) {
+        if (tid < 32) {                                                        // (visible after the first interval's barrier)
+            const int m = min(tid, mlimit - 1), st = m >> 4, co = m & 15;
+            s_epi[tid] = p.bias[st * p.coeff_stem + co]; s_epi[32 + tid] = p.bnScale[st * p.coeff_stem + co]; s_epi[64 + tid] = p.bnShift[st * p.coeff_stem + co];
+        }
+    }
+    auto row_off = [&](int r) __attribute__((always_inline)) -> size_t {      // element offset of accumulator register r's (stem, channel) plane
+        if constexpr (NW == 4) return ob[r];
+        else return (size_t)(r >> 3) * p.out_stem + (size_t)((r & 3) + 8 * ((r >> 2) & 1)) * ohw;       // mt = 0; the lane's + 4 half channels sit in pix0
+    };
     // activation of each 16-row stem group (registers 0..7 / 8..15)
     const int stg0 = min(2 * mt, p.stack - 1), stg1 = min(2 * mt + 1, p.stack - 1);
     const SrtAct apg[2] = { srt_act_params(((p.elu_mask >> stg0) & 1u) ? SRT_ACT_ELU : p.act, p.variant), srt_act_params(((p.elu_mask >> stg1) & 1u) ? SRT_ACT_ELU : p.act, p.variant) };
     const bool ok_lo = mt * 32 < mlimit, ok_hi = mt * 32 + 16 < mlimit;         // wave-uniform: registers 0..7 are one stem's channels, 8..15 the next stem's
     const int nst = ABL == 1 ? 0 : ((ok_lo ? 8 : 0) + (ok_hi ? 8 : 0)) * (H16 ? 2 : 1);          // stores this wave issues per interval
     const int oyl = 2 * reg + (l31 >> 4), oxl = 4 * (l31 & 15);
-    const size_t pix0 = (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl;
+    const size_t pix0 = (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl + (NW == 4 ? (size_t)0 : (size_t)(4 * half) * ohw);
     float* outp = p.outRaw + pix0;
     // ---- DMA: float4 e = piece * 64 + lane of a chunk = (row * 2 + ch) * 36 + j  <-  channel ch, image row 8 c + row, columns 2 ox0 - 4 + 4 j .. + 3
     constexpr unsigned OOR = 0x80000000u;
     const size_t hw = (size_t)p.H * p.W;
-    unsigned voff[3]; int vrow[3]; unsigned pdst[3];
+    unsigned voff[PPW]; unsigned pdst[PPW];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_ring;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int piece = min(wave + 4 * q, NPIECE - 1), e = piece * 64 + lane;
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = min(wave + NW * q, NPIECE - 1), e = piece * 64 + lane;
         const int j = e % (PITCH / 4), rc = e / (PITCH / 4), ch = rc & 1, row = rc >> 1, gx = 2 * ox0 - 4 + 4 * j;
-        vrow[q] = row;
         voff[q] = (j < 34 && gx >= 0 && gx + 3 < p.W) ? 4u * (unsigned)((size_t)ch * hw + (size_t)row * p.W + gx) : OOR;
         pdst[q] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(piece * 1024));
     }
@@ -513,19 +532,21 @@ __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvP
     auto dma_chunk = [&](int c) {
         const unsigned adv = 4u * (unsigned)(8 * c * p.W), base = (unsigned)((c & 3) * 8 * 2 * PITCH * 4);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const unsigned vo = (voff[q] != OOR && 8 * c + vrow[q] < p.H) ? voff[q] + adv : OOR;
+        for (int q = 0; q < PPW; ++q) {
+            const unsigned vo = (voff[q] != OOR && 8 * c < p.H) ? voff[q] + adv : OOR;       // (H % 8 == 0, checked by the launcher: a chunk is inside the image or below it)
             const unsigned dst = pdst[q] + base;
             asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo), "s"(rs), "s"(dst) : "memory");
         }
     };
-    // image row -1 (ring row 31) is zero padding; chunk 3 overwrites it long after interval 0 has read it
-    for (int e = tid; e < 2 * PITCH; e += 256) s_ring[31 * 2 * PITCH + e] = 0.0f;
-    dma_chunk(0); dma_chunk(1);
+    const int nint = Ho / 4 / nparts, i0 = part * nint;                         // this workgroup's intervals i0 .. i0 + nint - 1 (the launcher checks Ho / 4 % nparts == 0)
+    if (i0 == 0) {
+        // image row -1 (ring row 31) is zero padding; chunk 3 overwrites it long after interval 0 has read it
+        for (int e = tid; e < 2 * PITCH; e += NW * 64) s_ring[31 * 2 * PITCH + e] = 0.0f;
+    } else dma_chunk(i0 - 1);                                                  // a run that starts inside the column: its row 8 i0 - 1 is the last row of the chunk above
+    dma_chunk(i0); dma_chunk(i0 + 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
     const int lcol = 2 * oxl + 3;                                              // ring column of input column 2 ox - 1 (kx = 0, nr = 0)
-    const int nint = Ho / 4;
-    for (int i = 0; i < nint; ++i) {
+    for (int i = i0; i < i0 + nint; ++i) {
         // my pieces of chunk i + 1 (issued during interval i - 1, before its 16 stores) have landed; the stores may still be in flight
         if (nst == 32) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));      // vmcnt(32)
         else if (nst == 16) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14)); // vmcnt(16)
@@ -557,18 +578,21 @@ __global__ void __launch_bounds__(256, 2) srt_down1_stream_kernel(const SrtConvP
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < 8 ? ok_lo : ok_hi) {
+                    float b_, sc_ = 0.0f, sf_ = 0.0f;
+                    if constexpr (EPI_LDS) { const int row = (r & 3) + 8 * (r >> 2) + 4 * half; b_ = s_epi[row]; sc_ = s_epi[32 + row]; sf_ = s_epi[64 + row]; }
+                    else { b_ = bi[r]; if constexpr (H16) { sc_ = sc2[r]; sf_ = sf2[r]; } }
                     float4 v;
-                    v.x = acc[0][r] + bi[r]; v.y = acc[1][r] + bi[r]; v.z = acc[2][r] + bi[r]; v.w = acc[3][r] + bi[r];
+                    v.x = acc[0][r] + b_; v.y = acc[1][r] + b_; v.z = acc[2][r] + b_; v.w = acc[3][r] + b_;
                     if constexpr (H16) {
                         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                        const size_t eo = pix0 + (size_t)(4 * i) * Wo + ob[r];
+                        const size_t eo = pix0 + (size_t)(4 * i) * Wo + row_off(r);
                         h4 hv, ha;
                         hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
-                        ha[0] = (_Float16)srt_enc_epilogue(v.x, sc2[r], sf2[r], apg[r >> 3]); ha[1] = (_Float16)srt_enc_epilogue(v.y, sc2[r], sf2[r], apg[r >> 3]);
-                        ha[2] = (_Float16)srt_enc_epilogue(v.z, sc2[r], sf2[r], apg[r >> 3]); ha[3] = (_Float16)srt_enc_epilogue(v.w, sc2[r], sf2[r], apg[r >> 3]);
+                        ha[0] = (_Float16)srt_enc_epilogue(v.x, sc_, sf_, apg[r >> 3]); ha[1] = (_Float16)srt_enc_epilogue(v.y, sc_, sf_, apg[r >> 3]);
+                        ha[2] = (_Float16)srt_enc_epilogue(v.z, sc_, sf_, apg[r >> 3]); ha[3] = (_Float16)srt_enc_epilogue(v.w, sc_, sf_, apg[r >> 3]);
                         *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.outRaw) + eo) = hv;
                         *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.outAct) + eo) = ha;
-                    } else *reinterpret_cast<float4*>(orow + ob[r]) = v;
+                    } else *reinterpret_cast<float4*>(orow + row_off(r)) = v;
                 }
             }
         }
@@ -1094,7 +1118,23 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
     const int Wo = p.W / 2;
     if (p.Cin == 2) {                                                                    // down1, stem-stacked M
         if (!p.wpack2 || p.stack < 1 || p.Cout != 16) return 1;       // the stacked epilogue maps 16 rows to a stem
-        if (p.stack * p.Cout <= 32) return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+        if (p.stack * p.Cout <= 32) {
+            // one M tile (one or two stems), batches that give every CU four two-wave column workgroups: the streamed form with NW = 2, each column cut into two runs
+            const int Ho = p.H / 2;
+            const bool h16 = p.out16 && p.outAct && p.bnScale && p.bnShift;
+            const char* dv = getenv("SPLEETERRT_D1S2");                        // (=0: the tiled kernel - A/B runs and the parity test, which switches it inside one process)
+            const bool d1s2 = !(dv && dv[0] == '0');
+            if (d1s2 && SRT_DOWN1_STREAM_DEFAULT && p.CP2 >= 64 && (!p.out16 || h16) && !p.ws && Wo % 64 == 0 && Ho % 8 == 0 && (long)(Wo / 64) * p.ntiles * 2 >= 768 &&
+                (size_t)p.stack * p.out_stem < ((size_t)1 << 32) && (size_t)8 * p.H * p.W < 0x7fffffffu) {
+                SrtConvParams q = p;
+                q.rowsplit = 2;
+                const dim3 grid((unsigned)((Wo / 64) * p.ntiles * q.rowsplit));
+                if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true, 2>), grid, dim3(128), 0, s, q);
+                else SRT_LAUNCH((srt_down1_stream_kernel<0, false, 2>), grid, dim3(128), 0, s, q);
+                return srt_launch_status();
+            }
+            return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
+        }
         // batches that give every CU two column workgroups: the streamed form (bit-identical to the tiled one; see srt_down1_stream_kernel)
         {
             const int Ho = p.H / 2;

@@ -193,6 +193,58 @@ def test_up6_streamed_form(oracle, coeffs, T, F, ntiles, stems):
     print("up6 streamed %dx%d x%d x%d: worst tap rel-rms %.3g, max-abs/peak %.3g" % (T, F, ntiles, stems, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("T,F,ntiles,stems,precision", [
+    (64, 512, 96, 1, "f32"),        # one stem: half an M tile; 4 columns x 96 tiles x 2 runs of 4 intervals
+    (64, 512, 96, 2, "f16"),        # two stems: one full M tile, fp16 storage (raw + act(BN(.)) as halves, epilogue constants from LDS)
+    (128, 256, 192, 5, "f16"),      # BASELINE configs[4]'s five stems: four on the four-wave form, the fifth here; 2 columns x 192 tiles x 2 runs of 8 intervals
+    (64, 512, 97, 5, "f32"),        # ... on fp32 tensors, odd tile count
+])
+def test_down1_streamed_two_wave_form(oracle, coeffs, T, F, ntiles, stems, precision):
+    """Round 6: launches of one M tile (one or two stems, e.g. the fifth stem of five) run down1 as srt_down1_stream_kernel<.., NW = 2> (csrc/srt_nn2.hip: two waves per
+    column workgroup, each column cut into two runs of intervals) instead of the tiled kernel.  Same MFMA chain per output: conv1 and the act1 tap must be BIT-IDENTICAL to the
+    tiled form (SPLEETERRT_D1S2=0) on the first, an interior and the last tile - including the rows either side of the cut between the two runs - the engine must name the
+    kernel, and the masks hold the mode's tolerance against the oracle."""
+    import os
+    import torch
+    import spleeterrt_amd as srt
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    kw = dict(precision=srt.PREC_F16) if precision == "f16" else dict(impl=srt.IMPL_MFMA)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, **kw)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    x = _mag_input(oracle, ntiles, T, F, seed=8800 + T + F + stems)
+    xd = torch.from_numpy(x).cuda()
+    last = stems - 1                                             # the stem(s) of the remainder group
+    picks = [(last, t) for t in sorted({0, ntiles // 2, ntiles - 1})]
+    old = os.environ.get("SPLEETERRT_D1S2")
+    try:
+        os.environ["SPLEETERRT_D1S2"] = "0"
+        m0 = eng.forward(xd).cpu().numpy().copy()
+        k0 = _layer_kernels(eng, xd)
+        assert "srt_enc_mfma2<" in k0["down1"], k0["down1"]
+        ref = {(n,) + st: eng.tensor(n, *st) for st in picks for n in ("conv1", "act1")}
+        os.environ["SPLEETERRT_D1S2"] = "1"
+        m1 = eng.forward(xd).cpu().numpy()
+        k1 = _layer_kernels(eng, xd)
+        assert "srt_down1_stream_kernel<0, %s, 2>" % ("true" if precision == "f16" else "false") in k1["down1"], k1["down1"]
+        for key, want in ref.items():
+            got = eng.tensor(key[0], key[1], key[2])
+            assert np.array_equal(got, want), (key, int((got != want).sum()))
+        assert np.array_equal(m0, m1)
+    finally:
+        if old is None:
+            os.environ.pop("SPLEETERRT_D1S2", None)
+        else:
+            os.environ["SPLEETERRT_D1S2"] = old
+    tol = 2e-2 if precision == "f16" else MASK_TOL_EXACT
+    for s, t in picks:
+        y = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST)
+        assert float(np.abs(m1[s, t] - y).max()) <= tol, (s, t)
+    if precision == "f32":
+        _check_taps(eng, oracle, coeffs(last), x[picks[1][1]], modes[last], last, picks[1][1], m1, "down1 two-wave")
+    eng.close()
+
+
 @pytest.mark.parametrize("T,F,ntiles,stems,precision,variant", [
     (64, 512, 33, 4, "f32", "vst"),       # four full 64-pixel columns per instance, 132 instances; exact sigmoid
     (64, 576, 29, 4, "f32", "lut"),       # W = 288: a 32-pixel last column (the right image edge inside the halo the head needs); table sigmoid
