@@ -472,7 +472,8 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     const bool small = few && e->ws;
     // fp16 storage, launches above 16 instances: the tensors between down2 and up5 are kept channel-interleaved by eight and the layers run on the DMA-fed
     // kernels of srt_nn5.hip (SPLEETERRT_C8=0: the planar kernels of srt_nn3.hip everywhere, for A/B runs)
-    static const bool c8_env = []() { const char* v = getenv("SPLEETERRT_C8"); return !(v && v[0] == '0'); }();
+    const char* c8v = getenv("SPLEETERRT_C8");                                     // (read per forward: parity tests compare the two layouts inside one process)
+    const bool c8_env = !(c8v && c8v[0] == '0');
     const bool c8 = e->act16 && !few && c8_env;
     e->last_c8 = c8;
     {
@@ -610,6 +611,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.srcB = eoff(e, e->up[i - 1], (size_t)s0 * ntiles * e->up_tile[i - 1]); p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];
             }
             p.in16 = e->act16; p.out16 = e->act16 && i < 5;
+            p.c8srcB = c8 && i == 5;                                            // up6 reads up5's C8 output (its skip input, down1's raw tensor, stays planar)
             p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
             p.coeff_stem = SRT_COEFF_STRIDE;
             p.wpack = e->wpack_up[i] + (size_t)s0 * e->wpack_up_stem[i]; p.wpack_stem = e->wpack_up_stem[i];
@@ -626,7 +628,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             if (e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_up[i]) {
                 p.wpack16 = e->wpack16_up[i] + (size_t)s0 * e->wpack16_up_stem[i]; p.wpack16_stem = e->wpack16_up_stem[i];
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
-                if (c8 && i < 5) {                                              // C8 in; C8 out (up1..up4) or planar out (up5, class-stacked weights)
+                if (c8 && i < 5) {                                              // C8 in, C8 out (up5: class-stacked weights)
                     p.wpack16cs = e->wpack16cs_u5 + (size_t)s0 * SRT_W16CS_U5; p.wpack16cs_stem = SRT_W16CS_U5;
                     rc2 = srt_launch_dec_c8(p, e->stream);
                     if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for a decoder layer");
@@ -1087,9 +1089,9 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     const bool halves = e->act16 && !(name[0] == 'u' && idx == 5);           // up6 (the head's input) is always fp32
     const float* src = halves ? eoff(e, const_cast<float*>(base), ((size_t)stem * e->last_ntiles + tile) * per) : base + ((size_t)stem * e->last_ntiles + tile) * per;
     float* tmp = nullptr;
-    // raw2..raw6 (and the act taps derived from them) and up1..up4 of a large fp16-storage batch are channel-interleaved by eight (srt_nn5.hip): the tap
+    // raw2..raw6 (and the act taps derived from them) and up1..up5 of a large fp16-storage batch are channel-interleaved by eight (srt_nn5.hip): the tap
     // is returned planar, like every other
-    const bool c8 = halves && e->last_c8 && ((name[0] == 'u') ? idx <= 3 : idx >= 1);
+    const bool c8 = halves && e->last_c8 && ((name[0] == 'u') ? idx <= 4 : idx >= 1);
     float* planar = nullptr;
     if (c8) {
         const int C = name[0] == 'u' ? DEC_CH[idx][1] : ENC_CH[idx][1];

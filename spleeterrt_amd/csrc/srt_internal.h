@@ -79,6 +79,7 @@ struct SrtConvParams {
     // ((c/8) H W + y W + x) 8 + c % 8 - the B-fragment layout of the fp16 MFMA, so patches go HBM -> LDS by DMA alone).  c8out: srt_enc_f16 (down2: planar
     // input) stores its raw + act outputs in that form.  wpack16cs: up5's class-stacked fp16 weights [Cin/16][15][2][32][8] (srt_pack16_classstack_kernel).
     int c8out;
+    int c8srcB;           // up6 (srt_nn.hip): srcB = up5's output holds its 16 channels C8 (two groups of 8) instead of planar; srcA (down1's raw skip) stays planar
     const uint16_t* wpack16cs; size_t wpack16cs_stem;
     float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
     float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)

@@ -12,8 +12,9 @@
 // A workgroup is 8 waves, one 32-pixel sub-tile each, sharing one 32-row weight slab per 16-channel K chunk; it walks `tpw` consecutive (instance group, tile)
 // units of one (stem, M block) as ONE stream of K steps through an LDS ring (patch + slab per stage): the DMA of step s+1 (s+2 in the decoder) is in flight under
 // the MFMAs of step s across unit boundaries, and a unit's epilogue is issued right after the next step's DMA, in its shadow.  One barrier per step.
-// Tensors in C8: raw2..raw6, act2..act5, up1..up4 (srt_engine.hip: forward_range, `c8`); down1 / down2's input / up5's output / up6 stay planar, so
-// srt_down1_stream_kernel and srt_up6_stream_kernel are untouched: down2 (srt_enc_f16) only switches its epilogue, up5 runs here with planar stores.
+// Tensors in C8: raw2..raw6, act2..act5, up1..up5 (srt_engine.hip: forward_range, `c8`); down1's outputs (down2's input, up6's skip) stay planar, so
+// srt_down1_stream_kernel is untouched and down2 (srt_enc_f16) only switches its epilogue; up5 runs here class-stacked and the up6 kernels (srt_nn.hip) take
+// its 16 channels as one ds_read_b128 / one 16-byte load per B fragment (SrtConvParams::c8srcB).
 #include "srt_device.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -333,10 +334,10 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
     if (worker) epilogue();
 }
 
-// ------------------------------------------------------------------------------------------- decoder, C8 in -> C8 out (or planar out: up5)
+// ------------------------------------------------------------------------------------------- decoder, C8 in -> C8 out
 // Transposed 5x5 stride-2 convolution as four parity classes of the output (srt_nn3.hip: srt_dec_f16); 32-pixel INPUT sub-tiles, all four classes accumulated
 // from one B fragment per input shift.  CS (up5, Cout = 16): class-stacked weights - 32 rows = 2 x-classes x 16 channels, 15 (ky, dx)
-// products per chunk, two accumulators (one per row class) - and planar fp16 stores (srt_up6_stream_kernel reads planar halves).  LW: see srt_enc_c8.
+// products per chunk, two accumulators (one per row class).  LW: see srt_enc_c8.
 // WPE (waves per SIMD the kernel is built for): 1 - one workgroup per CU's worth of registers.  4 - TWO workgroups per CU (<= 128 VGPRs: the epilogue constants
 // come from LDS instead of 48 registers): two independent barrier domains on a CU, so one workgroup's epilogue / DMA issue runs under the other's MFMAs - the overlap
 // the eight lock-stepped waves of one workgroup cannot give each other (ablation matrix in DESIGN.md 3.2).
@@ -470,10 +471,8 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
             const int tile = (unit / nsp) * NI + il_w[n], a = (sp / tilesX) * TH + a_l[n], b = (sp % tilesX) * TW + b_l;
             pix_ok[n] = tile < p.ntiles && a < p.H && b < p.W;
             const size_t pix = pix_ok[n] ? (size_t)(2 * a) * Wo + 2 * b : 0;
-            // C8 out: the lane stores output column 2 b + g of its pixel pair (c8_pair16).  CS (planar out): even lanes store channel 8 qq + 4 g + j of a pair
-            // (j, j + 1), odd lanes channel j + 1, four output columns 4 (b / 2) .. + 3 each
-            obase[n] = stem * p.out_stem + (pix_ok[n] ? tile : 0) * p.out_tile +
-                       (CS ? pix - (pix_ok[n] ? 2 * (b_l & 1) : 0) : ((size_t)(m0 / 8) * ohw + pix + (pix_ok[n] ? g : 0)) * 8);
+            // C8 out: the lane stores output column 2 b + g of its pixel pair (c8_pair16); CS: the layer's 16 channels are channel groups 0 and 1
+            obase[n] = stem * p.out_stem + (pix_ok[n] ? tile : 0) * p.out_tile + ((size_t)(CS ? 0 : m0 / 8) * ohw + pix + (pix_ok[n] ? g : 0)) * 8;
         }
     };
     f32x16 acc[NR][NACC];
@@ -483,29 +482,25 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             if constexpr (CS) {
-                // rows of the MFMA tile: m = 8 q + 4 g + j = px * 16 + co  ->  px = q >> 1, co = 8 (q & 1) + 4 g + j: the two x-classes of a channel are one packed
-                // pair = two neighbouring output columns.  Neighbouring lanes (input columns b, b + 1) trade one channel each (DPP quad_perm [1, 0, 3, 2]): 8-byte stores.
-                const bool odd = (lane & 1) != 0;
+                // rows of the MFMA tile: m = 8 q + 4 g + j = px * 16 + co  ->  px = q >> 1, co = 8 (q & 1) + 4 g + j: the lane's four values of (q, py) are half of the
+                // C8 slot (channel group q & 1, output column 2 b + px), lane + 32 holds the other half - the same exchange as below with the two x-classes as the
+                // slot pair: 16-byte stores, 1 KiB of whole lines per wave instruction (round 6: up5's output is C8 too; srt_up6_* read it as B fragments)
 #pragma unroll
-                for (int py = 0; py < 2; ++py)
+                for (int cgp = 0; cgp < 2; ++cgp)
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq)
+                    for (int py = 0; py < 2; ++py) {
+                        h4 v[2];
 #pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            unsigned d[2];
+                        for (int px = 0; px < 2; ++px)
 #pragma unroll
-                            for (int jj = 0; jj < 2; ++jj) {
-                                const int r0 = 4 * qq + j + jj, r1 = 4 * (qq + 2) + j + jj;              // (bias / BN of r0 and r1 are the same channel's)
-                                const f2 o = c8_dec_pair(F2(acc[n][py][r0], acc[n][py][r1]), F2(bi[r0], bi[r1]), F2(sc[r0], sc[r1]), F2(sf[r0], sf[r1]), actp);
-                                const h2 hv = { (_Float16)o.x, (_Float16)o.y };
-                                d[jj] = __builtin_bit_cast(unsigned, hv);
+                            for (int j = 0; j < 4; j += 2) {
+                                const int r = 4 * (2 * px + cgp) + j;
+                                const f2 o = c8_dec_pair(F2(acc[n][py][r], acc[n][py][r + 1]), F2(bi[r], bi[r + 1]), F2(sc[r], sc[r + 1]), F2(sf[r], sf[r + 1]), actp);
+                                v[px][j] = (_Float16)o.x; v[px][j + 1] = (_Float16)o.y;
                             }
-                            const unsigned send = odd ? d[0] : d[1];                                   // the even lane's channel j + 1 value goes to the odd lane, the odd lane's channel j value to the even one
-                            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);
-                            const u32x2 v = odd ? (u32x2){ recv, d[1] } : (u32x2){ d[0], recv };
-                            const int co = 8 * qq + 4 * g + j + (odd ? 1 : 0);
-                            if (pix_ok[n]) *reinterpret_cast<u32x2*>(outh + obase[n] + (size_t)co * ohw + (size_t)py * Wo) = v;
-                        }
+                        const u32x4 o16 = c8_pair16(v[0], v[1]);
+                        if (pix_ok[n]) *reinterpret_cast<u32x4*>(outh + obase[n] + ((size_t)cgp * ohw + (size_t)py * Wo) * 8) = o16;
+                    }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -528,7 +523,7 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
     };
 
     int du = unit0, dch = 0, cu = unit0, ch = 0, issued = 0;
-    constexpr int NST = 8;                                     // LW = 0: store instructions of one epilogue (C8 out: 4 groups x 2 rows of 16 B; planar out: 2 rows x 4 channel pairs of 8 B); pinned by tests/test_abi.py
+    constexpr int NST = CS ? 4 : 8;                            // LW = 0: store instructions of one epilogue (4 channel groups x 2 rows of 16 B; class-stacked: 2 groups x 2 rows); pinned by tests/test_abi.py
     bool pending = false;                                      // this wave issued them in the previous step (wave-uniform; never on a loader-only wave)
     auto issue_next = [&]() {                                  // the step after the last one issued (always exactly DPW instructions: past the end, the last step again - harmless, its stage is free)
         issue_dma(dch, issued % ST, issued >= ST);

@@ -221,7 +221,7 @@ def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     txt = asm.read_text().split("\n")
     kernels = [m.group(1) for m in (re.match(r"(_Z10srt_(?:enc|dec)_c8I\w+):", l) for l in txt) if m]
-    assert len(kernels) == 6, kernels                       # 2 tile shapes x (encoder, decoder C8 out, decoder planar out); the LW = 1 forms exist in the tuning library only
+    assert len(kernels) == 6, kernels                       # 2 tile shapes x (encoder, decoder, class-stacked decoder); the LW = 1 forms exist in the tuning library only
     for mangled in kernels:
         start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
         end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
@@ -240,12 +240,13 @@ def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
             if not lw:                                      # LW = 0: the wait allows the 4 (2 without the act copy: down6) stores behind the DMA
                 assert 4 in waits and 2 in waits and 0 in waits, (mangled, waits)
         else:
-            planar_out = targs[4] == 1
-            assert stores == ["global_store_dwordx2" if planar_out else "global_store_dwordx4"] * (16 * nr), (mangled, stores)
+            cs = targs[4] == 1                              # class-stacked (up5, Cout = 16): two channel groups x two rows of 16-byte stores per epilogue, 15 weight rows per chunk
+            nst = 4 if cs else 8
+            assert stores == ["global_store_dwordx4"] * (2 * nst * nr), (mangled, stores)
             nlw = 4 if lw else 8
             npp = {32: 11, 16: 14}[sw]                      # patch pieces of 1 KiB per stage
-            dpw = -(-npp // nlw) + -(-(15 if planar_out else 25) // nlw)     # DMA instructions per loader wave and K step
+            dpw = -(-npp // nlw) + -(-(15 if cs else 25) // nlw)     # DMA instructions per loader wave and K step
             assert dpw in waits, (mangled, dpw, waits)      # ring depth 3: one step's pieces may stay in flight
             if not lw:
-                assert dpw + 8 in waits, (mangled, waits)   # ... + the NST = 8 epilogue stores issued behind them
+                assert dpw + nst in waits, (mangled, waits) # ... + the NST epilogue stores issued behind them
         assert len([l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]) >= 2

@@ -271,7 +271,9 @@ def test_up6_and_head_in_one_pass(oracle, coeffs, T, F, ntiles, stems, precision
     x = _mag_input(oracle, ntiles, T, F, seed=7700 + T + F)
     xd = torch.from_numpy(x).cuda()
     old = os.environ.get("SPLEETERRT_FUSE_HEAD")
+    old_c8 = os.environ.get("SPLEETERRT_C8")
     try:
+        os.environ["SPLEETERRT_C8"] = "0"                         # the one-pass form reads planar tensors only (fp16 storage: the planar kernels of srt_nn3.hip in front of it)
         os.environ["SPLEETERRT_FUSE_HEAD"] = "0"
         two = eng.forward(xd).cpu().numpy().copy()
         k2 = _layer_kernels(eng, xd)
@@ -287,11 +289,14 @@ def test_up6_and_head_in_one_pass(oracle, coeffs, T, F, ntiles, stems, precision
         assert np.array_equal(one, two), "masks differ: %d values, worst %g" % (int((one != two).sum()), float(np.abs(one - two).max()))
         for st in picks:
             assert np.array_equal(eng.tensor("up6", *st), planes[st]), st
+        for _ in range(2):                                       # run-to-run stability of the one-pass form
+            assert np.array_equal(eng.forward(xd).cpu().numpy(), one)
     finally:
-        if old is None:
-            os.environ.pop("SPLEETERRT_FUSE_HEAD", None)
-        else:
-            os.environ["SPLEETERRT_FUSE_HEAD"] = old
+        for k, v in (("SPLEETERRT_FUSE_HEAD", old), ("SPLEETERRT_C8", old_c8)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     tol = 2e-2 if precision == "f16" else (MASK_TOL_EXACT if variant == "vst" else MASK_TOL_LUT)
     worst = 0.0
     for s, t in picks:
@@ -792,8 +797,8 @@ def test_config4_five_stems_fp16_end_to_end(oracle, coeffs, prec, mask_tol, stem
 def test_more_than_four_stems_down1_groups(oracle, coeffs, modes, ntiles, F):
     """Five and six sub-networks in fp32 (round 5): down1 goes out as stacked groups of four stems + the remainder (4 + 1, 4 + 2), each group with its own
     slice of weights, bias, outputs and activation bits.  Mixed LeakyReLU / ELU stems so that a wrong shift of the activation mask shows; the 48-tile case
-    puts the first group on the streamed down1 kernel (8 column strips x 48 tiles = 384 workgroups) and the remainder on the tiled one.  Every tensor of
-    the checked instances against the oracle (spleeter.c:182-300)."""
+    puts the first group on the streamed down1 kernel (8 column strips x 48 tiles = 384 workgroups) and the remainder - one M tile - on its two-wave form
+    (round 6: 8 x 48 x 2 runs = 768 workgroups of two waves).  Every tensor of the checked instances against the oracle (spleeter.c:182-300)."""
     import torch
     import spleeterrt_amd as srt
     T, S = 64, len(modes)
@@ -806,7 +811,7 @@ def test_more_than_four_stems_down1_groups(oracle, coeffs, modes, ntiles, F):
     kern = None
     if ntiles >= 48:
         eng.set_timing(True); eng.forward(torch.from_numpy(x).cuda(), masks); kern = [k for n, k in eng.get_timing_kernels() if n == "down1"]; eng.set_timing(False)
-        assert len(kern) == 2 and kern[0].startswith("srt_down1_stream_kernel") and kern[1].startswith("srt_enc_mfma2"), kern
+        assert len(kern) == 2 and kern[0].startswith("srt_down1_stream_kernel<0, false, 4>") and kern[1].startswith("srt_down1_stream_kernel<0, false, 2>"), kern
     masks = masks.cpu().numpy()
     for s, t in ((0, 0), (3, ntiles - 1), (4, 0), (S - 1, ntiles - 1), (1, ntiles // 2)):
         _check_taps(eng, oracle, cs[s], x[t], modes[s], s, t, masks=masks, tag="%d stems" % S)
