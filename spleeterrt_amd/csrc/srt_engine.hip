@@ -117,6 +117,7 @@ struct srt_engine {
     bool act16;                                        // raw[0..5] and up[0..4] hold IEEE halves (precision F16 on a supported geometry)
     uint16_t* wpack16cs_u5;                            // act16 only: up5's class-stacked fp16 weights [n_stems][4][15][2][32][8] (srt_nn5.hip)
     SrtConvParams up6_params; int up6_s0; unsigned up6_stale;          // the last forward ran up6 + head in one pass (no up6 plane stored): srtCopyTensor("up6") re-launches up6 alone from these
+    bool last_c8_l1;                                   // ... and conv1 / act1 too (down1 ran on its streamed kernels)
     bool last_c8;                                      // the last forward stored raw2..6 / act2..5 / up1..4 channel-interleaved by eight (srt_nn5.hip): srtCopyTensor's view
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
@@ -212,7 +213,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
     memset(e->wino_e, 0, sizeof e->wino_e); memset(e->wino_e_stem, 0, sizeof e->wino_e_stem); memset(e->act32, 0, sizeof e->act32);
-    e->wpack16cs_u5 = nullptr; e->last_c8 = false; e->up6_stale = 0; e->up6_s0 = 0;
+    e->wpack16cs_u5 = nullptr; e->last_c8 = false; e->last_c8_l1 = false; e->up6_stale = 0; e->up6_s0 = 0;
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -475,7 +476,10 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     const char* c8v = getenv("SPLEETERRT_C8");                                     // (read per forward: parity tests compare the two layouts inside one process)
     const bool c8_env = !(c8v && c8v[0] == '0');
     const bool c8 = e->act16 && !few && c8_env;
-    e->last_c8 = c8;
+    // ... and down1's two outputs (raw1: up6's skip input, act1: down2's input) where down1 runs on its streamed kernels (SPLEETERRT_C8L1=0: planar, for A/B runs)
+    const char* c8l1v = getenv("SPLEETERRT_C8L1");
+    const bool c8_l1 = c8 && !(c8l1v && c8l1v[0] == '0') && e->cfg.impl == SRT_IMPL_MFMA && srt_down1_c8_ok(T, F, ntiles, (size_t)ntiles * e->raw_tile[0]);
+    e->last_c8 = c8; e->last_c8_l1 = c8_l1;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
         unsigned elu_mask = 0;
@@ -515,6 +519,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.out_stem = (size_t)ntiles * e->raw_tile[i]; p.out_tile = e->raw_tile[i];
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
+            if (i == 0) p.c8out = c8_l1;
             if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
                 // more than four sub-networks (BASELINE configs[4]: five): the streamed down1 kernel stacks at most 4 x 16 rows, so the first whole groups of
                 // four go out here, each as its own stacked launch; the remainder (1..4 stems) follows the common path below
@@ -574,7 +579,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             if (rc2 == 1 && e->cfg.impl == SRT_IMPL_MFMA && e->wpack16_down[i]) {
                 p.wpack16 = e->wpack16_down[i] + (size_t)s0 * e->wpack16_down_stem[i]; p.wpack16_stem = e->wpack16_down_stem[i];
                 p.nsplit = e->cfg.precision == SRT_PREC_F16X2 ? 2 : 1;
-                if (c8 && i >= 2) {                                             // C8 in, C8 out (srt_nn5.hip)
+                if (c8 && (i >= 2 || c8_l1)) {                                  // C8 in, C8 out (srt_nn5.hip); down2 when down1 wrote its act copy C8
                     rc2 = srt_launch_enc_c8(p, e->stream);
                     if (rc2 == 1) return fail(-4, "internal: C8 activation layout but no C8 kernel for an encoder layer");
                 } else {
@@ -611,7 +616,8 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
                 p.srcB = eoff(e, e->up[i - 1], (size_t)s0 * ntiles * e->up_tile[i - 1]); p.srcB_stem = (size_t)ntiles * e->up_tile[i - 1]; p.srcB_tile = e->up_tile[i - 1];
             }
             p.in16 = e->act16; p.out16 = e->act16 && i < 5;
-            p.c8srcB = c8 && i == 5;                                            // up6 reads up5's C8 output (its skip input, down1's raw tensor, stays planar)
+            p.c8srcB = c8 && i == 5;                                            // up6 reads up5's C8 output
+            p.c8srcA = c8_l1 && i == 5;                                         // ... and down1's raw tensor, its skip input, where that is C8 too
             p.wraw = cbase + L.w; p.bias = cbase + L.b; p.bnShift = cbase + L.bn; p.bnScale = cbase + L.bn + L.cout;
             p.coeff_stem = SRT_COEFF_STRIDE;
             p.wpack = e->wpack_up[i] + (size_t)s0 * e->wpack_up_stem[i]; p.wpack_stem = e->wpack_up_stem[i];
@@ -1091,7 +1097,7 @@ int srtCopyTensor(srt_engine* e, const char* name, int stem, int tile, float* h_
     float* tmp = nullptr;
     // raw2..raw6 (and the act taps derived from them) and up1..up5 of a large fp16-storage batch are channel-interleaved by eight (srt_nn5.hip): the tap
     // is returned planar, like every other
-    const bool c8 = halves && e->last_c8 && ((name[0] == 'u') ? idx <= 4 : idx >= 1);
+    const bool c8 = halves && e->last_c8 && ((name[0] == 'u') ? idx <= 4 : (idx >= 1 || e->last_c8_l1));
     float* planar = nullptr;
     if (c8) {
         const int C = name[0] == 'u' ? DEC_CH[idx][1] : ENC_CH[idx][1];

@@ -79,7 +79,8 @@ struct SrtConvParams {
     // ((c/8) H W + y W + x) 8 + c % 8 - the B-fragment layout of the fp16 MFMA, so patches go HBM -> LDS by DMA alone).  c8out: srt_enc_f16 (down2: planar
     // input) stores its raw + act outputs in that form.  wpack16cs: up5's class-stacked fp16 weights [Cin/16][15][2][32][8] (srt_pack16_classstack_kernel).
     int c8out;
-    int c8srcB;           // up6 (srt_nn.hip): srcB = up5's output holds its 16 channels C8 (two groups of 8) instead of planar; srcA (down1's raw skip) stays planar
+    int c8srcB;           // up6 (srt_nn.hip): srcB = up5's output holds its 16 channels C8 (two groups of 8) instead of planar
+    int c8srcA;           // ... and so does srcA, down1's raw skip tensor (batches whose down1 runs on the streamed kernels: srt_down1_c8_ok)
     const uint16_t* wpack16cs; size_t wpack16cs_stem;
     float* outRaw;        // encoder: conv+bias (the skip tensor AND the next encoder layer's input); decoder: unused
     float* outAct;        // decoder: bn(act(v)); encoder: unused (the BN + activation is applied by the consumer)
@@ -108,6 +109,7 @@ int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, h
 int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 // v2 kernels (srt_nn2.hip): return 1 when the layer geometry is not covered (caller falls back to the v1 kernels)
 int  srt_launch_enc2(const SrtConvParams& p, hipStream_t s);
+int  srt_down1_c8_ok(int H, int W, int ntiles, size_t out_stem);   // fp16 storage: down1 of this batch runs on the streamed kernels, which can write raw1 / act1 C8
 int  srt_launch_dec2(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack_stemstack(const float* coeff_w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s);
 int  srt_launch_pack_classstack(const float* w, float* wp2, int Cin, int Cout, hipStream_t s);

@@ -723,8 +723,9 @@ __global__ void __launch_bounds__(256, OCC) srt_up6_kernel(const SrtConvParams p
         if (IN16) {
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                if (kg == 1 && p.c8srcB) {                    // up5's output stored C8 (srt_nn5.hip): the lane's eight channels of the pixel are one 16-byte slot of group `half`
-                    const srt_h8 v = *reinterpret_cast<const srt_h8*>(reinterpret_cast<const _Float16*>(p.srcB) + stem * p.srcB_stem + tile * p.srcB_tile + ((size_t)half * hw + off) * 8);
+                if (kg == 1 ? p.c8srcB : p.c8srcA) {          // the tensor is stored C8 (srt_nn5.hip): the lane's eight channels of the pixel are one 16-byte slot of group `half`
+                    const _Float16* cb = kg == 1 ? reinterpret_cast<const _Float16*>(p.srcB) + stem * p.srcB_stem + tile * p.srcB_tile : reinterpret_cast<const _Float16*>(p.srcA) + stem * p.srcA_stem + tile * p.srcA_tile;
+                    const srt_h8 v = *reinterpret_cast<const srt_h8*>(cb + ((size_t)half * hw + off) * 8);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) b16[i][kg][q] = ok ? v[q] : (_Float16)0.0f;
                     continue;
@@ -807,12 +808,14 @@ typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
 // H16 (fp16 activation storage): the two source tensors hold halves - 16-byte DMA pieces are 8 pixels, a patch row is tx0 - 8 .. tx0 + 71 - and the
 // contraction is the tiled fp16 kernel's (srt_up6_kernel<.., true>: two v_mfma_f32_32x32x16_f16 per 32 pixels, weights rounded to fp16, the same
 // operands in the same order): bit-identical to it, half the input bytes.
-// BC8 (H16 only, round 6): srcB - up5's output - is stored C8 (SrtConvParams::c8srcB): its half of a chunk lands as 16-byte pixel slots and the second MFMA's B fragment is
-// one ds_read_b128 instead of eight 2-byte reads and their packing.  Same values into the same MFMAs: bit-identical to the planar form.
-template <int TW, int CR, int ABL = 0, bool H16 = false, bool BC8 = false>  // ABL (tuning builds, wrong results): 1 no DMA, 2 DMA only, 3 no gather
+// C8M (H16 only, round 6; bit 0: srcA - down1's raw skip tensor, bit 1: srcB - up5's output): the tensor is stored C8 (SrtConvParams::c8srcA / c8srcB): its half of a
+// chunk lands as 16-byte pixel slots and its MFMA's B fragment is one ds_read_b128 instead of eight 2-byte reads and their packing.  Same values into the same MFMAs:
+// bit-identical to the planar form.
+template <int TW, int CR, int ABL = 0, bool H16 = false, int C8M = 0>       // ABL (tuning builds, wrong results): 1 no DMA, 2 DMA only, 3 no gather
 __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvParams p)
 {
-    static_assert(!BC8 || H16, "C8 tensors hold halves");
+    static_assert(C8M == 0 || H16, "C8 tensors hold halves");
+    constexpr bool AC8 = (C8M & 1) != 0, BC8 = (C8M & 2) != 0;
     constexpr int CIN = 32, CAH = 16;
     constexpr int EPP = H16 ? 8 : 4, ESZ = H16 ? 2 : 4, LEAD = EPP - 1;      // elements per 16-byte DMA piece; bytes per element; patch column of pixel tx0 - 1
     constexpr int PW = TW + 2, SEG = TW / EPP + 2, PROW = SEG * EPP;         // pixels of a chunk row incl. halo; 16-byte segments per row (from tx0 - EPP)
@@ -862,10 +865,10 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
         const int j = e % SEG, row = (e / SEG) % CR, chl = (e / CHF4) % CAH, gx = tx0 - EPP + EPP * j;
         prow[q] = row;
         c0[q] = (gx >= 0 && gx + EPP - 1 < p.W) ? (unsigned)ESZ * (unsigned)((size_t)chl * hw + (size_t)row * p.W + gx) : OOR;
-        if constexpr (BC8) {
-            // srcB = up5's output in C8: the second half of a chunk is [channel group 2][row CR][pixel PROW] slots of 16 bytes (the same 5 pieces), slot <- 8 channels of one pixel
-            if (piece >= NPIECE / 2) {
-                const int e2 = e - (NPIECE / 2) * 64, px = e2 % PROW, row2 = (e2 / PROW) % CR, gq = e2 / (PROW * CR), gxp = tx0 - EPP + px;
+        if constexpr (C8M != 0) {
+            // a source tensor in C8: its half of a chunk is [channel group 2][row CR][pixel PROW] slots of 16 bytes (the same 5 pieces), slot <- 8 channels of one pixel
+            if (piece >= NPIECE / 2 ? BC8 : AC8) {
+                const int e2 = e % ((NPIECE / 2) * 64), px = e2 % PROW, row2 = (e2 / PROW) % CR, gq = e2 / (PROW * CR), gxp = tx0 - EPP + px;
                 prow[q] = row2;
                 c0[q] = (gxp >= 0 && gxp < p.W) ? 16u * (unsigned)((size_t)gq * hw + (size_t)row2 * p.W + gxp) : OOR;
             }
@@ -882,7 +885,7 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
             const int piece = min(wave + NDW * q, NPIECE - 1);                // wave-uniform (a piece past the last one repeats it)
-            const unsigned advq = (BC8 && piece >= NPIECE / 2) ? 16u * (unsigned)(i * CR * p.W) : adv;      // C8 rows are 16 bytes per pixel
+            const unsigned advq = (piece >= NPIECE / 2 ? BC8 : AC8) ? 16u * (unsigned)(i * CR * p.W) : adv;      // C8 rows are 16 bytes per pixel
             const unsigned voff = (c0[q] != OOR && i * CR + prow[q] < p.H) ? c0[q] + advq : OOR;
             const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(piece * 1024));
             if (piece < NPIECE / 2) asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsA), "s"(dst) : "memory");
@@ -911,11 +914,14 @@ __global__ void __launch_bounds__(512, 2) srt_up6_stream_kernel(const SrtConvPar
                 const _Float16* bsrc = reinterpret_cast<const _Float16*>(s_p) + (i & 1) * PBUF + (half * 8 * CR + row) * PROW + col + LEAD;
                 srt_h8 b16[2];
 #pragma unroll
-                for (int kg = 0; kg < (BC8 ? 1 : 2); ++kg)
+                for (int kg = 0; kg < 2; ++kg) {
+                    if (kg == 0 ? AC8 : BC8) {                                  // the tensor's eight channels of the pixel: ONE aligned 16-byte slot of channel group `half`
+                        b16[kg] = *reinterpret_cast<const srt_h8*>(reinterpret_cast<const _Float16*>(s_p) + (i & 1) * PBUF + kg * (PBUF / 2) + ((half * CR + row) * PROW + col + LEAD) * 8);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) b16[kg][q] = bsrc[(kg * 16 + q) * CR * PROW];
-                if constexpr (BC8)                                             // up5's channels of the pixel: ONE aligned 16-byte slot of channel group `half`
-                    b16[1] = *reinterpret_cast<const srt_h8*>(reinterpret_cast<const _Float16*>(s_p) + (i & 1) * PBUF + PBUF / 2 + ((half * CR + row) * PROW + col + LEAD) * 8);
+                        for (int q = 0; q < 8; ++q) b16[kg][q] = bsrc[(kg * 16 + q) * CR * PROW];
+                    }
+                }
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[kg], b16[kg], acc, 0, 0, 0);
             } else {
@@ -1243,7 +1249,7 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
 {
     if ((p.in16 || p.out16) && !(impl == 0 && p.Cout == 1 && p.Cin == 32 && !p.out16)) return -1;   // only up6 reads fp16 tensors here
     if (impl != 0) return launch_naive(srt_dec_naive, p, (size_t)p.Cout * p.H * p.W * 4, s);
-    if (p.c8srcB && !p.in16) return -1;
+    if ((p.c8srcB || p.c8srcA) && !p.in16) return -1;
     if (p.Cout == 1 && p.Cin == 32) {                                                         // up6
 #define UP6_LAUNCH(TH, TW) SRT_LAUNCH((srt_up6_kernel<TH, TW, 32>), dim3(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.nstems * p.ntiles), dim3(256), 0, s, p)
         int v = 0;
@@ -1254,7 +1260,9 @@ int srt_launch_dec(const SrtConvParams& p, int impl, hipStream_t s)
         // fp32 tensors, batches that fill the chip with column workgroups (2 per CU): the streamed form
         const long cols = (long)((p.W + 63) / 64) * p.nstems * p.ntiles;
         if (p.CA == 16 && p.W % (p.in16 ? 8 : 4) == 0 && p.srcA && p.srcB && (size_t)64 * p.H * p.W < 0x7fffffffu && ((cols >= 512 && v == 0 && SRT_UP6_STREAM_DEFAULT) || v == 11)) {
-            if (p.in16 && p.c8srcB) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 0, true, true>), dim3((unsigned)cols), dim3(512), 0, s, p);   // ... up5's output in C8
+            if (p.in16 && p.c8srcB && p.c8srcA) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 0, true, 3>), dim3((unsigned)cols), dim3(512), 0, s, p);   // ... both tensors in C8
+            else if (p.in16 && p.c8srcB) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 0, true, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);          // ... up5's output in C8
+            else if (p.c8srcA) return -1;
             else if (p.in16) SRT_LAUNCH((srt_up6_stream_kernel<64, 2, 0, true>), dim3((unsigned)cols), dim3(512), 0, s, p);       // halves in, fp32 out (fp16 activation storage)
             else SRT_LAUNCH((srt_up6_stream_kernel<64, 2>), dim3((unsigned)cols), dim3(512), 0, s, p);
             return srt_launch_status();
@@ -1302,7 +1310,7 @@ int srt_launch_up6_head(const SrtConvParams& p, const SrtHeadParams& h, hipStrea
     // up5's output in C8 (large fp16-storage batches, srt_nn5.hip): not covered.  A BC8 instantiation of this kernel (the same three edits as in srt_up6_stream_kernel) was
     // built and dropped: its masks differed from run to run in 16-lane pieces of single rows (first / last interval of the head, channel 0) while the planar form and the
     // BC8 form of the two-kernel path are stable - unexplained, and this form is slower anyway.
-    if (p.c8srcB) return 1;
+    if (p.c8srcB || p.c8srcA) return 1;
     if ((size_t)64 * p.H * p.W >= 0x7fffffffu || h.H != 2 * p.H || h.W != 2 * p.W || h.ntiles != p.ntiles || h.nstems != p.nstems) return 1;
     const long cols = (long)((p.W + 63) / 64) * p.nstems * p.ntiles;
     if (cols < 512) return 1;

@@ -462,10 +462,15 @@ typedef int srt_i32x4 __attribute__((ext_vector_type(4)));
 // much as the four stacked stems' streamed launch costs for its MFMAs alone).  The M tile mt = 1 has nothing to compute there, so the workgroup is the two mt = 0 waves
 // (half the MFMAs per interval), four workgroups per CU instead of two, and - to have that many - a column is cut into p.rowsplit runs of intervals, each started from
 // the three chunks around its first row.  Same chain per output as NW = 4: bit-identical.
-template <int ABL = 0, bool H16 = false, int NW = 4>                            // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
+// C8O (H16 only, round 6): both outputs leave channel-interleaved by eight (srt_nn5.hip: down2 then runs on the DMA-fed srt_enc_c8, up6 takes the skip tensor as one
+// 16-byte slot per B fragment).  A lane holds channels 4 half .. + 3 of a slot for four pixels, lane + 32 the other four channels: one v_permlane32_swap per dword
+// hands the low lane the whole slots of pixels 0 / 2 and the high lane those of pixels 1 / 3 - two 16-byte stores per (stem, channel group, output) where the planar
+// form has four 8-byte ones.
+template <int ABL = 0, bool H16 = false, int NW = 4, bool C8O = false>          // ABL (tuning builds, wrong results): 1 no stores, 2 no MFMAs
 __global__ void __launch_bounds__(NW * 64, 2) srt_down1_stream_kernel(const SrtConvParams p)
 {
     static_assert(NW == 4 || NW == 2, "four waves (two M tiles x two row pairs) or two (one M tile)");
+    static_assert(!C8O || H16, "C8 tensors hold halves");
     constexpr int PITCH = SRT_D1S_PITCH, RING = 32, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64, PPW = (NPIECE + NW - 1) / NW;      // 576 float4 = 9 pieces per chunk
     static_assert(CH_F4 % 64 == 0 && NPIECE == 9, "a chunk is whole DMA pieces");
     __shared__ __attribute__((aligned(16))) float s_ring[RING * 2 * PITCH];
@@ -509,7 +514,7 @@ __global__ void __launch_bounds__(NW * 64, 2) srt_down1_stream_kernel(const SrtC
     const int stg0 = min(2 * mt, p.stack - 1), stg1 = min(2 * mt + 1, p.stack - 1);
     const SrtAct apg[2] = { srt_act_params(((p.elu_mask >> stg0) & 1u) ? SRT_ACT_ELU : p.act, p.variant), srt_act_params(((p.elu_mask >> stg1) & 1u) ? SRT_ACT_ELU : p.act, p.variant) };
     const bool ok_lo = mt * 32 < mlimit, ok_hi = mt * 32 + 16 < mlimit;         // wave-uniform: registers 0..7 are one stem's channels, 8..15 the next stem's
-    const int nst = ABL == 1 ? 0 : ((ok_lo ? 8 : 0) + (ok_hi ? 8 : 0)) * (H16 ? 2 : 1);          // stores this wave issues per interval
+    const int nst = ABL == 1 ? 0 : ((ok_lo ? 8 : 0) + (ok_hi ? 8 : 0)) * (H16 && !C8O ? 2 : 1);   // stores this wave issues per interval (C8: 2 groups x 2 pixel pairs x 2 outputs per stem)
     const int oyl = 2 * reg + (l31 >> 4), oxl = 4 * (l31 & 15);
     const size_t pix0 = (size_t)tile * p.out_tile + (size_t)oyl * Wo + ox0 + oxl + (NW == 4 ? (size_t)0 : (size_t)(4 * half) * ohw);
     float* outp = p.outRaw + pix0;
@@ -574,6 +579,47 @@ __global__ void __launch_bounds__(NW * 64, 2) srt_down1_stream_kernel(const SrtC
             for (int nr = 0; nr < 4; ++nr) for (int r = 0; r < 16; ++r) acc[nr][r] = s_ring[ro[0] + nr + r];
         }
         float* orow = outp + (size_t)(4 * i) * Wo;
+        if constexpr (C8O) {
+            // registers 4 k .. 4 k + 3 = channels 4 half + 0..3 of channel group k & 1 of stem 2 mt + (k >> 1); slot (stem, group, pixel) at ((group ohw + pixel) 8) halves
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+            _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+            const size_t pixc = (size_t)tile * p.out_tile + ((size_t)(4 * i + oyl) * Wo + ox0 + oxl + half) * 8;      // the lane stores pixels oxl + half and oxl + 2 + half
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < 2 ? ok_lo : ok_hi) {
+                    const int st = 2 * mt + (k >> 1);
+                    const size_t so = (size_t)st * p.out_stem + (size_t)(k & 1) * ohw * 8 + pixc;
+                    h4 rv[4], av[4];                                        // per pixel: the lane's four channels
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * k + j;
+                        float b_, sc_, sf_;
+                        if constexpr (EPI_LDS) { const int row = (r & 3) + 8 * (r >> 2) + 4 * half; b_ = s_epi[row]; sc_ = s_epi[32 + row]; sf_ = s_epi[64 + row]; }
+                        else { b_ = bi[r]; sc_ = sc2[r]; sf_ = sf2[r]; }
+#pragma unroll
+                        for (int nr = 0; nr < 4; ++nr) {
+                            const float v = acc[nr][r] + b_;
+                            rv[nr][j] = (_Float16)v;
+                            av[nr][j] = (_Float16)srt_enc_epilogue(v, sc_, sf_, apg[k >> 1]);
+                        }
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const u32x2 ra = __builtin_bit_cast(u32x2, rv[2 * pr]), rb = __builtin_bit_cast(u32x2, rv[2 * pr + 1]);
+                        const u32x2 aa = __builtin_bit_cast(u32x2, av[2 * pr]), ab = __builtin_bit_cast(u32x2, av[2 * pr + 1]);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(ra.x, rb.x, false, false), r1 = __builtin_amdgcn_permlane32_swap(ra.y, rb.y, false, false);
+                        const auto a0 = __builtin_amdgcn_permlane32_swap(aa.x, ab.x, false, false), a1 = __builtin_amdgcn_permlane32_swap(aa.y, ab.y, false, false);
+                        if (ABL != 1 || p.ntiles < 0) {
+                            *reinterpret_cast<u32x4*>(rawh + so + (size_t)(2 * pr) * 8) = (u32x4){ r0[0], r1[0], r0[1], r1[1] };
+                            *reinterpret_cast<u32x4*>(acth + so + (size_t)(2 * pr) * 8) = (u32x4){ a0[0], a1[0], a0[1], a1[1] };
+                        }
+                    }
+                }
+            }
+        } else
         if (ABL != 1 || p.ntiles < 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1112,6 +1158,16 @@ static int launch_dec16(const SrtConvParams& p, hipStream_t s)
 }
 #endif
 
+// fp16 storage: can down1 of a T x F batch of ntiles tiles write its outputs C8, whatever the number of stems?  Only the streamed forms do (four-wave: groups of three
+// or four stems, two-wave: one or two), so this is their launch condition (see srt_launch_enc2) - H, W = the layer's INPUT size.
+int srt_down1_c8_ok(int H, int W, int ntiles, size_t out_stem)
+{
+    const char* dv = getenv("SPLEETERRT_D1S2");
+    const int Ho = H / 2, Wo = W / 2;
+    return SRT_DOWN1_STREAM_DEFAULT && !(dv && dv[0] == '0') && W % 4 == 0 && Wo % 64 == 0 && Ho % 8 == 0 && (long)(Wo / 64) * ntiles >= 384 &&
+           (size_t)4 * out_stem < ((size_t)1 << 32) && (size_t)8 * H * W < 0x7fffffffu;
+}
+
 int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
 {
     if (p.W % 4) return 1;
@@ -1129,10 +1185,12 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
                 SrtConvParams q = p;
                 q.rowsplit = 2;
                 const dim3 grid((unsigned)((Wo / 64) * p.ntiles * q.rowsplit));
-                if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true, 2>), grid, dim3(128), 0, s, q);
+                if (h16 && p.c8out) SRT_LAUNCH((srt_down1_stream_kernel<0, true, 2, true>), grid, dim3(128), 0, s, q);
+                else if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true, 2>), grid, dim3(128), 0, s, q);
                 else SRT_LAUNCH((srt_down1_stream_kernel<0, false, 2>), grid, dim3(128), 0, s, q);
                 return srt_launch_status();
             }
+            if (p.c8out) return -1;
             return launch_enc2_cfg<32, 1, 32, 2, 4, 1, 2, true>(p, s);
         }
         // batches that give every CU two column workgroups: the streamed form (bit-identical to the tiled one; see srt_down1_stream_kernel)
@@ -1150,10 +1208,12 @@ int srt_launch_enc2(const SrtConvParams& p, hipStream_t s)
                 if (streamed == 2) { SRT_LAUNCH((srt_down1_stream_kernel<1>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
                 if (streamed == 3) { SRT_LAUNCH((srt_down1_stream_kernel<2>), grid, dim3(256), 0, s, p); return srt_launch_status(); }
 #endif
-                if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true>), grid, dim3(256), 0, s, p);
+                if (h16 && p.c8out) SRT_LAUNCH((srt_down1_stream_kernel<0, true, 4, true>), grid, dim3(256), 0, s, p);
+                else if (h16) SRT_LAUNCH((srt_down1_stream_kernel<0, true>), grid, dim3(256), 0, s, p);
                 else SRT_LAUNCH((srt_down1_stream_kernel<0>), grid, dim3(256), 0, s, p);
                 return srt_launch_status();
             }
+            if (p.c8out) return -1;                                             // (the engine asks for C8 outputs only where srt_down1_c8_ok says the streamed forms run)
         }
 #ifdef SRT_TUNING
         switch (tune("down1")) {

@@ -174,7 +174,7 @@ def test_bench_roofline_peaks_follow_the_precision():
 def test_down1_stream_store_count_matches_its_vmcnt_wait(tmp_path):
     """srt_down1_stream_kernel proves "my LDS-DMA pieces have landed" with s_waitcnt vmcnt(nst), nst = the stores a wave issues per interval
     (8 per live 16-row stem group, x2 with fp16 storage).  That holds only if the compiler emits exactly ONE VM instruction per float4 / h4 store and spills
-    nothing to scratch.  Checked on the ISA of the four shipped instantiations (four-wave and two-wave form, fp32 and fp16 storage): store count, scratch size, and the
+    nothing to scratch.  Checked on the ISA of the six shipped instantiations (four-wave and two-wave form; fp32, planar fp16 and C8 fp16 outputs): store count, scratch size, and the
     vmcnt immediates of the kernel."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -185,8 +185,9 @@ def test_down1_stream_store_count_matches_its_vmcnt_wait(tmp_path):
                         "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "srt_nn2.hip"), "-o", str(asm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     txt = asm.read_text().split("\n")
-    for mangled, stores_per_group in (("_Z23srt_down1_stream_kernelILi0ELb0ELi4EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1ELi4EEv13SrtConvParams", 16),
-                                      ("_Z23srt_down1_stream_kernelILi0ELb0ELi2EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1ELi2EEv13SrtConvParams", 16)):   # NW = 2: the two-wave form (one M tile)
+    for mangled, stores_per_group in (("_Z23srt_down1_stream_kernelILi0ELb0ELi4ELb0EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1ELi4ELb0EEv13SrtConvParams", 16),
+                                      ("_Z23srt_down1_stream_kernelILi0ELb0ELi2ELb0EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1ELi2ELb0EEv13SrtConvParams", 16),   # NW = 2: the two-wave form (one M tile)
+                                      ("_Z23srt_down1_stream_kernelILi0ELb1ELi4ELb1EEv13SrtConvParams", 8), ("_Z23srt_down1_stream_kernelILi0ELb1ELi2ELb1EEv13SrtConvParams", 8)):    # C8 outputs: 16-byte stores, 8 per stem
         start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
         end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
         body = [l.strip() for l in txt[start:end] if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
