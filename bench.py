@@ -75,7 +75,7 @@ def executed_fraction(symbol, precision="f32"):
     """MFMA products the kernel executes / products of the layer's algorithm (the reference's direct convolution)"""
     if "wino" in symbol:
         return WINO_EXECUTED_FRACTION
-    if symbol.startswith("srt_dec_c8<") and symbol.rstrip("> ").endswith("true"):
+    if symbol.startswith("srt_dec_c8<") and [x.strip() for x in symbol.split("<", 1)[1].rstrip("> ").split(",")][4:5] == ["true"]:   # 5th template argument: CS
         return 15.0 * 32 / (25.0 * 16)      # up5, class-stacked: 15 products of 32 rows (2 x-classes x 16 channels) where the algorithm has 25 of 16 rows
     if precision == "f16x2" and "_f16<" in symbol:
         return 2.0                          # activations split hi + lo: two MFMAs per tap

@@ -164,6 +164,7 @@ def test_bench_roofline_peaks_follow_the_precision():
     assert bench.mfma_peak("srt_dec_wino32<2, 16, 0, 3, 2, 1, 1, 0, 1, 1, 1>") == 157.3 and bench.mfma_peak("srt_enc_mfma2<64, 2, 32, 2, 4, 1, 2, true, 0, false, false>") == 157.3
     assert bench.executed_fraction("srt_enc_f16<32, 1, 4, 1, 1, true>", "f16x2") == 2.0 and bench.executed_fraction("srt_enc_f16<32, 1, 4, 1, 1, true>", "f16") == 1.0
     assert bench.executed_fraction("srt_enc_wino32<2, 16, 1, 0>") == 0.49
+    assert bench.executed_fraction("srt_dec_c8<32, 8, 1, 3, true, 0>") == 1.2 and bench.executed_fraction("srt_dec_c8<32, 8, 1, 3, false, 0>") == 1.0   # class-stacked up5: 15 x 32 rows for 25 x 16
     # bytes: up2 at 256 x 1024 reads 512 channels of 8 x 32 and writes 128 of 16 x 64, fp32 / fp16 storage
     assert bench.layer_bytes("up2", "f32", False) == 512 * 8 * 32 * 4 + 128 * 16 * 64 * 4
     assert bench.layer_bytes("up2", "f16", True) == (512 * 8 * 32 + 128 * 16 * 64) * 2
