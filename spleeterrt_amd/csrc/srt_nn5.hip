@@ -341,13 +341,15 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
 // WPE (waves per SIMD the kernel is built for): 1 - one workgroup per CU's worth of registers.  4 - TWO workgroups per CU (<= 128 VGPRs: the epilogue constants
 // come from LDS instead of 48 registers): two independent barrier domains on a CU, so one workgroup's epilogue / DMA issue runs under the other's MFMAs - the overlap
 // the eight lock-stepped waves of one workgroup cannot give each other (ablation matrix in DESIGN.md 3.2).
-template <int SW, int NSY, int NI, int ST, bool CS, int LW, int ABL = 0, int WPE = 1>
+// NRW (LW = 0): sub-tiles per wave.  2 - a unit is SIXTEEN 32-pixel sub-tiles (16 x 32 input pixels): every A fragment read from LDS feeds two MFMAs, the 25 KiB weight slab of a
+// K step - 70 % of the bytes a step moves into LDS - is amortised over twice the outputs, and there is one barrier per 50 MFMAs of a wave instead of per 25.
+template <int SW, int NSY, int NI, int ST, bool CS, int LW, int ABL = 0, int WPE = 1, int NRW = 1>
 __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, int tpw)
 {
     constexpr bool EPI_LDS = WPE >= 4;
-    static_assert(NSY * NI == 8 && 32 % SW == 0 && ST >= 2 && ST <= 4, "eight 32-pixel sub-tiles");
+    constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : NRW;
+    static_assert(NSY * NI == (LW ? 4 : 8) * NR && 32 % SW == 0 && ST >= 2 && ST <= 4 && (NRW == 1 || (NRW == 2 && !LW)), "eight (NRW = 2: sixteen) 32-pixel sub-tiles");
     constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
-    constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : 1;
     constexpr int PH = TH + 2, PC = TW + 2;
     constexpr int PLANE = NI * PH * PC;
     constexpr int PITEMS = 2 * PLANE, NPP = (PITEMS + 63) / 64, PPW = (NPP + NLW - 1) / NLW;
@@ -523,8 +525,8 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
     };
 
     int du = unit0, dch = 0, cu = unit0, ch = 0, issued = 0;
-    constexpr int NST = CS ? 4 : 8;                            // LW = 0: store instructions of one epilogue (4 channel groups x 2 rows of 16 B; class-stacked: 2 groups x 2 rows); pinned by tests/test_abi.py
-    bool pending = false;                                      // this wave issued them in the previous step (wave-uniform; never on a loader-only wave)
+    constexpr int NST = CS ? 4 : 8;                            // LW = 0: store instructions of one sub-tile's epilogue (4 channel groups x 2 rows of 16 B; class-stacked: 2 groups x 2 rows); pinned by tests/test_abi.py
+    int pending = 0;                                           // sub-tiles whose stores this wave issued in the previous step (wave-uniform; never on a loader-only wave)
     auto issue_next = [&]() {                                  // the step after the last one issued (always exactly DPW instructions: past the end, the last step again - harmless, its stage is free)
         issue_dma(dch, issued % ST, issued >= ST);
         ++issued;
@@ -539,16 +541,23 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
             if (loader) {
                 // everything older than this wave's pieces of the ST-2 newest steps has landed: step s (+ the NST epilogue stores of the previous step, issued
                 // behind its DMA: vmcnt retires in issue order, see srt_enc_c8)
-                if (pending) __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW + NST));
+                if (NR == 2 && pending == 2) __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW + 2 * NST));
+                else if (pending) __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW + NST));
                 else __builtin_amdgcn_s_waitcnt(c8_vmcnt((ABL & 3) ? 0 : (ST - 2) * DPW));
             }
             __syncthreads();
         }
-        pending = false;
+        pending = 0;
         if (loader) issue_next();                              // step s + ST - 1 into the stage step s - 1 just left
         if (worker) {
             if (ch == 0) {
-                if (s > 0 && !(ABL & 8)) { epilogue(); if (!LW) pending = __builtin_amdgcn_ballot_w64(pix_ok[0]) != 0; }
+                if (s > 0 && !(ABL & 8)) {
+                    epilogue();
+                    if (!LW) {                                 // (a sub-tile with no pixel inside the image may or may not have issued its masked stores: counting it out errs on the waiting side)
+#pragma unroll
+                        for (int n = 0; n < NR; ++n) pending += __builtin_amdgcn_ballot_w64(pix_ok[n]) != 0 ? 1 : 0;
+                    }
+                }
                 set_out_unit(cu);
 #pragma unroll
                 for (int n = 0; n < NR; ++n)
@@ -675,6 +684,24 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
             return srt_launch_status();
         }
 #endif
+        // Two sub-tiles per wave (NRW = 2: units of 16 x 32 input pixels), round 6, same box, 5 stems: up3 0.327 -> 0.297 ms, up4 0.380 -> 0.346, up2 (one tile row per
+        // instance) 0.297 -> 0.297.  The class-stacked up5 measured SLOWER in this form (0.445 -> 0.487: its 15 KiB slab is the smaller part of a step and the unit's
+        // epilogue doubles), so it keeps one sub-tile per wave; its NRW = 2 instantiation is in the tuning library (SPLEETERRT_C8_NR2=3).  =0: one sub-tile everywhere (A/B runs).
+        const int nr2 = c8_env("SPLEETERRT_C8_NR2", 1);
+#ifndef SRT_TUNING
+        const bool cs2 = false;
+#else
+        const bool cs2 = cs && (nr2 & 2);
+#endif
+        if (p.H % 16 == 0 && (cs ? cs2 : (nr2 & 1) != 0)) {
+            const int nunits2 = ((p.W + TW - 1) / TW) * (p.H / 16) * p.ntiles, tpw2 = c8_tpw(nunits2, pairs);
+            const dim3 grid2((unsigned)(((nunits2 + tpw2 - 1) / tpw2) * pairs));
+#ifdef SRT_TUNING
+            if (cs) { SRT_LAUNCH((srt_dec_c8<32, 16, 1, 3, true, 0, 0, 1, 2>), grid2, dim3(512), 0, s, p, tpw2); return srt_launch_status(); }
+#endif
+            SRT_LAUNCH((srt_dec_c8<32, 16, 1, 3, false, 0, 0, 1, 2>), grid2, dim3(512), 0, s, p, tpw2);
+            return srt_launch_status();
+        }
         if (cs) C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0>), grid, dim3(512), 0, s, p, tpw));
         else C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     } else {

@@ -223,7 +223,7 @@ def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     txt = asm.read_text().split("\n")
     kernels = [m.group(1) for m in (re.match(r"(_Z10srt_(?:enc|dec)_c8I\w+):", l) for l in txt) if m]
-    assert len(kernels) == 6, kernels                       # 2 tile shapes x (encoder, decoder, class-stacked decoder); the LW = 1 forms exist in the tuning library only
+    assert len(kernels) == 7, kernels                       # 2 tile shapes x (encoder, decoder, class-stacked decoder) + the decoder with two sub-tiles per wave; the LW = 1 forms exist in the tuning library only
     for mangled in kernels:
         start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
         end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
@@ -236,7 +236,8 @@ def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
         targs = [int(x) for x in re.findall(r"L[ib](\d+)E", mangled)]
         enc = "srt_enc_c8" in mangled
         sw, lw = targs[0], targs[3] if enc else targs[5]
-        nr = 2 if lw else 1                                 # sub-tiles (hence epilogue copies of the stores) per computing wave
+        nrw = 1 if enc or len(targs) < 9 else targs[8]      # decoder: sub-tiles per wave of the LW = 0 form (NRW)
+        nr = 2 if lw else nrw                               # sub-tiles (hence epilogue copies of the stores) per computing wave
         if enc:                                             # raw + act: 2 + 2 sixteen-byte stores per sub-tile and epilogue
             assert stores == ["global_store_dwordx4"] * (8 * nr), (mangled, stores)
             if not lw:                                      # LW = 0: the wait allows the 4 (2 without the act copy: down6) stores behind the DMA
@@ -246,9 +247,14 @@ def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
             nst = 4 if cs else 8
             assert stores == ["global_store_dwordx4"] * (2 * nst * nr), (mangled, stores)
             nlw = 4 if lw else 8
-            npp = {32: 11, 16: 14}[sw]                      # patch pieces of 1 KiB per stage
+            nsy, ni = targs[1], targs[2]
+            th, tw = nsy * (32 // sw), sw
+            npp = -(-(2 * ni * (th + 2) * (tw + 2)) // 64)  # patch pieces of 1 KiB per stage (two k-groups of 16-byte pixel slots)
+            assert npp == {(32, 8): 11, (16, 2): 14, (32, 16): 20}[(sw, nsy)]
             dpw = -(-npp // nlw) + -(-(15 if cs else 25) // nlw)     # DMA instructions per loader wave and K step
             assert dpw in waits, (mangled, dpw, waits)      # ring depth 3: one step's pieces may stay in flight
             if not lw:
-                assert dpw + nst in waits, (mangled, waits) # ... + the NST epilogue stores issued behind them
+                assert dpw + nst in waits, (mangled, waits) # ... + the NST epilogue stores of one sub-tile issued behind them
+                if nr == 2:
+                    assert dpw + 2 * nst in waits, (mangled, waits)    # ... or of both
         assert len([l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]) >= 2
