@@ -141,8 +141,10 @@ int srt_launch_c8_to_float(const void* src, float* dst, int C, size_t hw, hipStr
 // ABL (SRT_TUNING builds only; wrong results): timing ablations - 1 no patch DMA after the ring is primed, 2 no weight DMA, 4 no MFMAs (and no LDS reads), 8 no
 // epilogue, 16 MFMAs on constant operands (no LDS reads), 32 no barrier / no DMA wait
 template <int SW, int NSY, int NI, int LW, int ABL = 0>
-__global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int tpw)
+__global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int tpw_)
 {
+    const int tpw = tpw_ & 0xffff;
+    const bool c8_weights_stay = (tpw_ >> 16) != 0;             // (launcher: SPLEETERRT_C8_WRES, default on)
     static_assert(NSY * NI == 8 && 32 % SW == 0, "eight 32-pixel sub-tiles");
     constexpr int SH = 32 / SW, TH = NSY * SH, TW = SW;
     constexpr int NLW = LW ? 4 : 8, NR = LW ? 2 : 1;            // waves that issue DMA; sub-tiles per computing wave
@@ -202,11 +204,14 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
         pa = reinterpret_cast<const _Float16*>(p.srcA) + stem * p.srcA_stem + tile0 * p.srcA_tile;
     };
     const unsigned chunk_bytes = (unsigned)(32 * hw);          // two C8 planes
+    // One K chunk per unit (down2, Cin = 16): every step of the workgroup multiplies by the SAME 25 KiB slab, so it is moved once per stage and stays - 25 of the
+    // 66 KiB a step used to move (the waits below count stores only, so a step with fewer DMA instructions needs no other bookkeeping).
+    const bool wres = nch == 1 && c8_weights_stay;
     auto issue_dma = [&](int ch, int stage, bool primed) {
         const unsigned sb = (unsigned)stage * (unsigned)(STAGE_H * 2);
         const i32x4 rs = c8_rsrc(pa, nrec);
         const _Float16* ws = wp + (size_t)ch * cgStride;
-        if (!((ABL & 2) && primed)) {
+        if (!(((ABL & 2) || wres) && primed)) {
 #pragma unroll
             for (int i = 0; i < WPW; ++i) c8_dma_global(wvoff[i], ws, wm0[i] + sb);
         }
@@ -653,7 +658,8 @@ int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s)
 #define C8_ENC_CASE(A) if (c8_abl() == A) { SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
         C8_ABL_CASES(C8_ENC_CASE)
 #endif
-        C8_LW(SRT_LAUNCH((srt_enc_c8<32, 8, 1, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0>), grid, dim3(512), 0, s, p, tpw));
+        const int tpwf = tpw | (c8_env("SPLEETERRT_C8_WRES", 1) != 0 ? 0x10000 : 0);         // (=0: the weight slab is moved every step even when a unit is one K chunk - A/B runs)
+        C8_LW(SRT_LAUNCH((srt_enc_c8<32, 8, 1, 1>), grid, dim3(512), 0, s, p, tpwf), SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0>), grid, dim3(512), 0, s, p, tpwf));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
         const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
