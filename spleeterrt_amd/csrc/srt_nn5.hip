@@ -18,6 +18,9 @@
 #include "srt_device.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -628,7 +631,13 @@ static int c8_env(const char* name, int dflt)
 #ifdef SRT_TUNING
 static bool c8_wpe4() { static const bool v = c8_env("SRT_TUNE_C8WPE", 1) == 4; return v; }
 #endif
-static int c8_target_wgs() { static const int v = c8_env("SPLEETERRT_C8_WGS", 1024) > 0 ? c8_env("SPLEETERRT_C8_WGS", 1024) : 1024; return v; }
+// Workgroups per launch (each walks its run of units as one stream of K steps).  Measured per layer at 64 tiles x 5 stems (round 6, SPLEETERRT_C8_WGS = 512 .. 4096 on one
+// box, profiles/r06_c8_wgs_sweep.json): the short-K full-resolution layers want long runs (down2 512: 0.357 ms against 0.375 at 1024; down3 / down4 768), the deep encoder layers
+// and the two-sub-tile decoder layers want many short ones (down5 / down6 1536: 0.181 against 0.196 / 0.199; up2..up4 1536: 0.270 / 0.270 / 0.313 against 0.298 / 0.298 / 0.347),
+// the class-stacked up5 1280.  SPLEETERRT_C8_WGS=<n> overrides them all (the sweep).
+// None of that transfers from five stems to four (there 1024 is as good as anything for most layers and 512 the best for some): what decides is how the runs fall
+// on the 256 CUs.  So the choice is MEASURED: the first launch of a layer shape times the candidates (c8_tuned below) and the process keeps the winner.
+static int c8_target_wgs(int dflt) { const int v = c8_env("SPLEETERRT_C8_WGS", 0); return v > 0 ? v : dflt; }
 // The loader-wave form (LW = 1) measured SLOWER on every layer but down5 / down6 (round 6, same box: 5-stem step 5.26 vs 5.09 ms; up4 0.434 vs 0.385): with one
 // computing wave per SIMD the MFMA stream loses more to its own LDS-read latency than the other waves lose to the DMA issue.  It is compiled into the tuning
 // library only (SRT_TUNE_C8LW=1); the product instantiates LW = 0.
@@ -638,21 +647,23 @@ static bool c8_lw() { static const bool v = c8_env("SRT_TUNE_C8LW", 0) != 0; ret
 #else
 #define C8_LW(then_, else_) do { else_; } while (0)
 #endif
-// units per workgroup: about c8_target_wgs() workgroups per launch (4 rounds of the 256 CUs), never across a (stem, M block) boundary
-static int c8_tpw(int nunits, int pairs)
+// units per workgroup: about `target` workgroups per launch, never across a (stem, M block) boundary
+static int c8_tpw(int nunits, int pairs, int target)
 {
-    const int upw = c8_target_wgs() / pairs > 0 ? c8_target_wgs() / pairs : 1;
+    const int upw = target / pairs > 0 ? target / pairs : 1;
     const int tpw = (nunits + upw - 1) / upw;
     return tpw < 1 ? 1 : tpw;
 }
 
-int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s)
+// target: workgroups per launch to aim for; 0 = SPLEETERRT_C8_WGS or the layer's table value
+static int enc_c8_launch(const SrtConvParams& p, hipStream_t s, int target)
 {
     if (!p.wpack16 || p.Cin % 16 || p.Cout % 32 || !p.in16 || !p.out16 || p.nsplit == 2 || p.inScale) return 1;
     const int Ho = p.H / 2, Wo = p.W / 2, pairs = (p.Cout / 32) * p.nstems;
     if (Wo > 16) {
         constexpr int TH = 8, TW = 32, NI = 1;
-        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        if (target <= 0) target = c8_target_wgs(p.Cin <= 64 ? 768 : 1536);
+        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs, target);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
 #ifdef SRT_TUNING
 #define C8_ENC_CASE(A) if (c8_abl() == A) { SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
@@ -662,14 +673,15 @@ int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s)
         C8_LW(SRT_LAUNCH((srt_enc_c8<32, 8, 1, 1>), grid, dim3(512), 0, s, p, tpwf), SRT_LAUNCH((srt_enc_c8<32, 8, 1, 0>), grid, dim3(512), 0, s, p, tpwf));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
-        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        if (target <= 0) target = c8_target_wgs(1536);
+        const int nunits = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs, target);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
         C8_LW(SRT_LAUNCH((srt_enc_c8<16, 2, 4, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_enc_c8<16, 2, 4, 0>), grid, dim3(512), 0, s, p, tpw));
     }
     return srt_launch_status();
 }
 
-int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
+static int dec_c8_launch(const SrtConvParams& p, hipStream_t s, int target)
 {
     const bool cs = p.Cout == 16;
     if (p.Cin % 16 || p.CA % 16 || !p.in16 || !p.out16 || p.nsplit == 2 || (cs ? !p.wpack16cs : (!p.wpack16 || p.Cout % 32 != 0))) return 1;
@@ -677,7 +689,8 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
     const int pairs = (cs ? 1 : p.Cout / 32) * p.nstems;
     if (p.W > 16) {
         constexpr int TH = 8, TW = 32, NI = 1;
-        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        if (target <= 0) target = c8_target_wgs(cs ? 1280 : 1536);
+        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs, target);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
 #ifdef SRT_TUNING
 #define C8_DEC_CASE(A) if (c8_abl() == A) { if (cs) SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, true, 0, A>), grid, dim3(512), 0, s, p, tpw); else SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0, A>), grid, dim3(512), 0, s, p, tpw); return srt_launch_status(); }
@@ -700,7 +713,7 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
         const bool cs2 = cs && (nr2 & 2);
 #endif
         if (p.H % 16 == 0 && (cs ? cs2 : (nr2 & 1) != 0)) {
-            const int nunits2 = ((p.W + TW - 1) / TW) * (p.H / 16) * p.ntiles, tpw2 = c8_tpw(nunits2, pairs);
+            const int nunits2 = ((p.W + TW - 1) / TW) * (p.H / 16) * p.ntiles, tpw2 = c8_tpw(nunits2, pairs, target);
             const dim3 grid2((unsigned)(((nunits2 + tpw2 - 1) / tpw2) * pairs));
 #ifdef SRT_TUNING
             if (cs) { SRT_LAUNCH((srt_dec_c8<32, 16, 1, 3, true, 0, 0, 1, 2>), grid2, dim3(512), 0, s, p, tpw2); return srt_launch_status(); }
@@ -712,7 +725,8 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
         else C8_LW(SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 1>), grid, dim3(512), 0, s, p, tpw), SRT_LAUNCH((srt_dec_c8<32, 8, 1, 3, false, 0>), grid, dim3(512), 0, s, p, tpw));
     } else {
         constexpr int TH = 4, TW = 16, NI = 4;
-        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs);
+        if (target <= 0) target = c8_target_wgs(1024);
+        const int nunits = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * ((p.ntiles + NI - 1) / NI), tpw = c8_tpw(nunits, pairs, target);
         const dim3 grid((unsigned)(((nunits + tpw - 1) / tpw) * pairs));
 #ifdef SRT_TUNING
         if (c8_wpe4()) {
@@ -726,3 +740,60 @@ int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s)
     }
     return srt_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------- measured workgroup counts
+// How many workgroups a C8 launch is cut into changes NOTHING in its results (a workgroup's run of units is only a partition of the same work) and up to 10 % of its
+// time, in a way that follows from how the runs fall on the 256 CUs and differs between four and five stems (see c8_target_wgs).  The first launch of a layer shape
+// therefore times the candidates on the caller's own tensors - one untimed launch each, then the best of three - and the process keeps the winner (about 5 ms per
+// layer shape, once).  No measuring inside a stream capture (the table value is used), none under SPLEETERRT_C8_WGS=<n> or SPLEETERRT_C8_TUNE=0.
+struct C8Key {
+    int v[10];
+    bool operator<(const C8Key& o) const { for (int i = 0; i < 10; ++i) if (v[i] != o.v[i]) return v[i] < o.v[i]; return false; }
+};
+static std::map<C8Key, int> g_c8_best;
+static std::mutex g_c8_mu;
+static int c8_tuned(int kind, const SrtConvParams& p, hipStream_t s)
+{
+    auto go = [&](int target) { return kind ? dec_c8_launch(p, s, target) : enc_c8_launch(p, s, target); };
+    // The bandwidth-heavy full-resolution layers (down2, down3, the class-stacked up5) are NOT measured: timed back to back on warm inputs they rank the candidates
+    // differently from how they run behind their producer in a step (round 6, 4 stems: the isolated winner was 8 % / 4 % / 3 % slower in the step); they keep table values
+    // that are within 2 % of the best at both four and five stems (768 / 768 / 1280).
+    const bool measured = kind ? p.Cout != 16 : p.Cin >= 64;
+    if (!measured || c8_env("SPLEETERRT_C8_WGS", 0) > 0 || c8_env("SPLEETERRT_C8_TUNE", 1) == 0) return go(0);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const C8Key key = {{ kind, p.Cin, p.Cout, p.H, p.W, p.ntiles, p.nstems, (p.outAct && p.bnScale) ? 1 : 0, c8_env("SPLEETERRT_C8_NR2", 1) * 2 + (c8_env("SPLEETERRT_C8_WRES", 1) != 0), dev }};
+    {
+        std::lock_guard<std::mutex> lk(g_c8_mu);
+        const auto it = g_c8_best.find(key);
+        if (it != g_c8_best.end()) return go(it->second);
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) { (void)hipGetLastError(); return go(0); }
+    const int rc0 = go(0);                                       // (not covered / a launch error: nothing to tune)
+    if (rc0) return rc0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) hipEventDestroy(e0); (void)hipGetLastError(); return 0; }
+    static const int cands[] = { 512, 768, 1024, 1280, 1536, 2048 };
+    int best = 0; float best_ms = 1e30f;
+    for (int c : cands) {
+        if (go(c)) { best = 0; break; }
+        float lo = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            float ms = 0.0f;
+            if (hipEventRecord(e0, s) != hipSuccess || go(c) || hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { lo = 1e30f; break; }
+            lo = ms < lo ? ms : lo;
+        }
+        if (lo < best_ms) { best_ms = lo; best = c; }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lk(g_c8_mu);
+        g_c8_best[key] = best;                                   // (0 if the timing failed: the table value from now on)
+    }
+    if (c8_env("SPLEETERRT_C8_TUNE", 1) >= 2) fprintf(stderr, "[spleeterrt_amd] C8 %s Cin %d Cout %d %dx%d x%d x%d: %d workgroups (%.3f ms)\n", kind ? "dec" : "enc", p.Cin, p.Cout, p.H, p.W, p.ntiles, p.nstems, best, best_ms);
+    return 0;                                                    // (the layer's outputs are in place: every candidate wrote the same values)
+}
+int srt_launch_enc_c8(const SrtConvParams& p, hipStream_t s) { return c8_tuned(0, p, s); }
+int srt_launch_dec_c8(const SrtConvParams& p, hipStream_t s) { return c8_tuned(1, p, s); }
