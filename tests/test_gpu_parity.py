@@ -337,7 +337,7 @@ def test_up6_streamed_form_fp16_storage(oracle, coeffs):
     eng.close()
 
 
-@pytest.mark.parametrize("T,F,ntiles,modes", [(64, 512, 9, (1, 0)), (128, 1024, 5, (1, 0, 1, 1)), (64, 256, 17, (0,)), (192, 768, 6, (1, 1, 0))])
+@pytest.mark.parametrize("T,F,ntiles,modes", [(64, 512, 9, (1, 0)), (128, 1024, 5, (1, 0, 1, 1)), (64, 256, 17, (0,)), (192, 768, 6, (1, 1, 0)), (256, 1024, 5, (0, 1, 1, 1))])   # the last: the bench tile geometry at an odd tile count (up2 = two instances of 8 x 32 per unit, the last group half empty)
 def test_fp16_c8_layers(oracle, coeffs, T, F, ntiles, modes):
     """fp16 storage, launches above 16 instances (round 6, csrc/srt_nn5.hip): the tensors between down2 and up5 are channel-interleaved by eight and down3..down6 /
     up1..up5 run on the DMA-fed kernels.  Every tensor of sampled instances (first, middle, last tile: the last one sits in a partly empty instance group of the deep
