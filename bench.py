@@ -65,6 +65,8 @@ def is_f16_kernel(symbol):
     """kernels of csrc/srt_nn3.hip (v_mfma_f32_32x32x16_f16), and up6 - tiled or streamed - when its inputs are halves (4th template argument)"""
     if "_f16<" in symbol or "_c8<" in symbol:          # csrc/srt_nn3.hip, and the C8-form kernels of csrc/srt_nn5.hip (same MFMA)
         return True
+    if symbol.startswith("srt_down1_f16_kernel<"):     # down1 of the fp16 mode (csrc/srt_nn2.hip)
+        return True
     if symbol.startswith("srt_up6_kernel<") or symbol.startswith("srt_up6_stream_kernel<"):
         args = symbol.split("<", 1)[1].rstrip("> ").split(",")
         return len(args) > 3 and args[3].strip().startswith("true")
@@ -77,6 +79,8 @@ def executed_fraction(symbol, precision="f32"):
         return WINO_EXECUTED_FRACTION
     if symbol.startswith("srt_dec_c8<") and [x.strip() for x in symbol.split("<", 1)[1].rstrip("> ").split(",")][4:5] == ["true"]:   # 5th template argument: CS
         return 15.0 * 32 / (25.0 * 16)      # up5, class-stacked: 15 products of 32 rows (2 x-classes x 16 channels) where the algorithm has 25 of 16 rows
+    if symbol.startswith("srt_down1_f16_kernel<"):
+        return 80.0 / 50.0                  # k-groups of 8 hold the 5 taps of one (channel, ky): 80 products per output where the algorithm has 50 (half-empty M tiles of odd stem counts not counted)
     if precision == "f16x2" and "_f16<" in symbol:
         return 2.0                          # activations split hi + lo: two MFMAs per tap
     return 1.0

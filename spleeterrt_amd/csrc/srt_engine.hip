@@ -520,7 +520,20 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
             p.act = actE; p.elu_mask = elu_mask; p.variant = e->cfg.variant;
             if (small) { p.ws = e->ws; p.ws_floats = e->ws_floats; }
             if (i == 0) p.c8out = c8_l1;
-            if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                       // stem-stacked M: all stems of the group share the input
+            // fp16 mode, C8 outputs: down1's products on the fp16 MFMA too, every stem of the call (up to six) in ONE launch (srt_down1_f16_kernel;
+            // SPLEETERRT_D1F16=0: the fp32-MFMA streamed kernels below, read per forward for A/B runs and the parity test)
+            if (i == 0 && c8_l1 && e->cfg.precision == SRT_PREC_F16 && p.nstems <= 6 && !small) {
+                const char* dv = getenv("SPLEETERRT_D1F16");
+                if (!(dv && dv[0] == '0')) {
+                    p.stack = p.nstems;
+                    TimerScope tg(e, "down1");
+                    const int rg = srt_launch_down1_f16(p, e->stream);
+                    if (rg == 0) continue;
+                    if (rg != 1) return fail(-2, "encoder launch failed");
+                    p.stack = 0;
+                }
+            }
+            if (i == 0 && e->cfg.impl == SRT_IMPL_MFMA) {                    // stem-stacked M: all stems of the group share the input
                 // more than four sub-networks (BASELINE configs[4]: five): the streamed down1 kernel stacks at most 4 x 16 rows, so the first whole groups of
                 // four go out here, each as its own stacked launch; the remainder (1..4 stems) follows the common path below
                 while (p.nstems > 4) {

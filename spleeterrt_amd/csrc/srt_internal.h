@@ -109,6 +109,7 @@ int  srt_launch_pack_enc(const float* w, float* wp, int Cin, int Cout, int CP, h
 int  srt_launch_pack_dec(const float* w, float* wp, int Cin, int Cout, int CP, hipStream_t s);
 // v2 kernels (srt_nn2.hip): return 1 when the layer geometry is not covered (caller falls back to the v1 kernels)
 int  srt_launch_enc2(const SrtConvParams& p, hipStream_t s);
+int  srt_launch_down1_f16(const SrtConvParams& p, hipStream_t s);   // fp16 mode, C8 outputs: down1 on the fp16 MFMA, p.stack = 1..6 stems in one launch (1: not covered)
 int  srt_down1_c8_ok(int H, int W, int ntiles, size_t out_stem);   // fp16 storage: down1 of this batch runs on the streamed kernels, which can write raw1 / act1 C8
 int  srt_launch_dec2(const SrtConvParams& p, hipStream_t s);
 int  srt_launch_pack_stemstack(const float* coeff_w0, size_t coeff_stem, int nstems, float* wp2, int Cin, int Cout, int CP2, hipStream_t s);

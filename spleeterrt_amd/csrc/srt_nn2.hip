@@ -645,6 +645,168 @@ __global__ void __launch_bounds__(NW * 64, 2) srt_down1_stream_kernel(const SrtC
     }
 }
 
+// ------------------------------------------------------------------------------------------- down1 of the fp16 mode on the fp16 MFMA
+// srt_config.precision F16 asks for fp16 products in the convolutions; down1 used to be the exception (the streamed kernel above with halves stored): 100 fp32
+// MFMAs = 6400 matrix cycles per wave and interval beside its stores, and at most four stems per launch (BASELINE configs[4]'s fifth went out as a second launch).
+// Here the same column walk - same LDS ring of fp32 magnitudes, same DMA, same counted wait - feeds v_mfma_f32_32x32x16_f16:
+//   k-group of 8 = the five taps kx of one (input channel, ky) + three zero weights; MFMA ky holds channel 0 in the k-groups of lanes 0..31 and channel 1 in those
+//   of lanes 32..63, so the conv is 5 MFMAs per 32 x 32 output block (30 per wave and interval for five stems: 960 matrix cycles) and every stem of the launch
+//   (MT M tiles of two stems) multiplies the SAME B fragments;
+//   wave w owns output row 4 i + w of the interval, lane l31 of sub-tile nr the pixel 2 l31 + nr: the seven input columns 4 l31 + 3 .. + 9 of a ring row serve
+//   both sub-tiles (three aligned LDS reads per ky), rounded to halves as they are packed;
+//   the epilogue is the C8 one of the kernel above with ONE lane-exchange pair per slot: a wave stores 64 consecutive 16-byte slots per (stem, channel group, output).
+// Weights come straight from the reference layout (OIHW, rounded to halves like every other layer's pack in this mode).  Not bit-identical to the fp32-MFMA forms:
+// the magnitudes are rounded to 11 bits first - the rounding this mode applies to every other activation (tests/test_gpu_parity.py::test_down1_fp16_mfma_form).
+typedef _Float16 srt_d1h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 srt_d1h4 __attribute__((ext_vector_type(4)));
+template <int MT>
+__global__ void __launch_bounds__(256, 2) srt_down1_f16_kernel(const SrtConvParams p)
+{
+    constexpr int PITCH = SRT_D1S_PITCH, RING = 32, NW = 4, CH_F4 = 8 * 2 * PITCH / 4, NPIECE = CH_F4 / 64, PPW = (NPIECE + NW - 1) / NW;
+    static_assert(CH_F4 % 64 == 0 && NPIECE == 9, "a chunk is whole DMA pieces");
+    static_assert(MT >= 1 && MT <= 3, "one to six stems");
+    __shared__ __attribute__((aligned(16))) float s_ring[RING * 2 * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_epi[3 * 32 * MT];          // bias | BN scale | BN shift of the stacked rows
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = p.H >> 1, Wo = p.W >> 1, strips = Wo / 64;
+    const int pos = srt_xcd_order(strips * p.ntiles), ox0 = (pos % strips) * 64, tile = pos / strips;
+    const int mlimit = p.stack * 16;
+    // A fragments: row m = 32 mt + l31 = (stem, channel), k = 8 half + kx: w[stem][co][ch = half][ky][kx], zero for kx > 4 and for rows past the last stem
+    srt_d1h8 a[MT][5];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 32 + l31;
+        const bool ok = m < mlimit;
+        const float* w = p.wraw + (size_t)(ok ? m >> 4 : 0) * p.coeff_stem + (size_t)(((ok ? m & 15 : 0) * 2 + half) * 25);
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) a[mt][ky][kx] = (kx < 5 && ok) ? (_Float16)w[ky * 5 + (kx < 5 ? kx : 0)] : (_Float16)0.0f;
+        }
+    }
+    if (tid < 32 * MT) {                                                       // (visible after the first interval's barrier)
+        const int m = min(tid, mlimit - 1), st = m >> 4, co = m & 15;
+        s_epi[tid] = p.bias[st * p.coeff_stem + co]; s_epi[32 * MT + tid] = p.bnScale[st * p.coeff_stem + co]; s_epi[64 * MT + tid] = p.bnShift[st * p.coeff_stem + co];
+    }
+    const size_t ohw = (size_t)Ho * Wo;
+    // ---- DMA: as srt_down1_stream_kernel (float4 e = piece * 64 + lane of a chunk = (row * 2 + ch) * 36 + j  <-  channel ch, image row 8 c + row, columns 2 ox0 - 4 + 4 j .. + 3)
+    constexpr unsigned OOR = 0x80000000u;
+    const size_t hw = (size_t)p.H * p.W;
+    unsigned voff[PPW]; unsigned pdst[PPW];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_ring;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = min(wave + NW * q, NPIECE - 1), e = piece * 64 + lane;
+        const int j = e % (PITCH / 4), rc = e / (PITCH / 4), ch = rc & 1, row = rc >> 1, gx = 2 * ox0 - 4 + 4 * j;
+        voff[q] = (j < 34 && gx >= 0 && gx + 3 < p.W) ? 4u * (unsigned)((size_t)ch * hw + (size_t)row * p.W + gx) : OOR;
+        pdst[q] = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(piece * 1024));
+    }
+    const size_t src_ = (size_t)(p.srcA + (size_t)tile * p.srcA_tile);
+    srt_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)src_); rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(src_ >> 32) & 0xffffu));
+    rs.z = (int)(unsigned)min((size_t)0x7fffffff, (size_t)8 * hw); rs.w = 0x00020000;
+    auto dma_chunk = [&](int c) {
+        const unsigned adv = 4u * (unsigned)(8 * c * p.W), base = (unsigned)((c & 3) * 8 * 2 * PITCH * 4);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const unsigned vo = (voff[q] != OOR && 8 * c < p.H) ? voff[q] + adv : OOR;
+            const unsigned dst = pdst[q] + base;
+            asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo), "s"(rs), "s"(dst) : "memory");
+        }
+    };
+    const int nint = Ho / 4;
+    for (int e = tid; e < 2 * PITCH; e += NW * 64) s_ring[31 * 2 * PITCH + e] = 0.0f;     // image row -1 (ring row 31): zero padding; chunk 3 overwrites it long after interval 0 has read it
+    dma_chunk(0); dma_chunk(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                         // vmcnt(0)
+    _Float16* rawh = reinterpret_cast<_Float16*>(p.outRaw);
+    _Float16* acth = reinterpret_cast<_Float16*>(p.outAct);
+    const size_t pix0 = (size_t)tile * p.out_tile + ((size_t)wave * Wo + ox0 + 2 * l31 + half) * 8;      // the lane stores the slot of pixel 2 l31 + half
+    for (int i = 0; i < nint; ++i) {
+        // my pieces of chunk i + 1 (issued during interval i - 1, before its 4 x stack stores) have landed; the stores may still be in flight
+        switch (p.stack) {
+        case 6: __builtin_amdgcn_s_waitcnt(0x0F70 | (24 & 15) | ((24 >> 4) << 14)); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F70 | (20 & 15) | ((20 >> 4) << 14)); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14)); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0F70 | 12); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F70 | 8); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70 | 4); break;
+        }
+        __syncthreads();                                                        // everyone's pieces; everyone is done with chunk i - 2 (the slot chunk i + 2 lands in)
+        dma_chunk(i + 2);                                                       // (past the image: zeros)
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const float* row = s_ring + ((((8 * i + 2 * wave + ky - 1) & (RING - 1)) * 2 + half) * PITCH) + 4 * l31;
+            const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+            const float2 v2 = *reinterpret_cast<const float2*>(row + 8);
+            srt_d1h8 b0, b1;                                                    // input columns 2 ox - 1 + kx of pixel ox = 2 l31 + nr: ring columns 4 l31 + 2 nr + 3 + kx
+            b0[0] = (_Float16)v0.w; b0[1] = (_Float16)v1.x; b0[2] = (_Float16)v1.y; b0[3] = (_Float16)v1.z; b0[4] = (_Float16)v1.w; b0[5] = b0[6] = b0[7] = (_Float16)0.0f;
+            b1[0] = b0[2]; b1[1] = b0[3]; b1[2] = b0[4]; b1[3] = (_Float16)v2.x; b1[4] = (_Float16)v2.y; b1[5] = b1[6] = b1[7] = (_Float16)0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ky == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b0, z, 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b1, z, 0, 0, 0);
+                } else {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][ky], b0, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][ky], b1, acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+        // registers 4 k .. 4 k + 3 of M tile mt = channels 4 half + 0..3 of channel group k & 1 of stem 2 mt + (k >> 1); slot (stem, group, pixel) at ((group ohw + pixel) 8) halves
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const size_t pixc = pix0 + (size_t)(4 * i) * Wo * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int st = 2 * mt + (k >> 1);
+                if (st < p.stack) {                                             // wave-uniform
+                    const SrtAct ap = srt_act_params(((p.elu_mask >> st) & 1u) ? SRT_ACT_ELU : p.act, p.variant);
+                    const size_t so = (size_t)st * p.out_stem + (size_t)(k & 1) * ohw * 8 + pixc;
+                    const int row0 = 32 * mt + 8 * k + 4 * half;
+                    const float4 b4 = *reinterpret_cast<const float4*>(s_epi + row0), sc4 = *reinterpret_cast<const float4*>(s_epi + 32 * MT + row0),
+                                 sf4 = *reinterpret_cast<const float4*>(s_epi + 64 * MT + row0);
+                    const float bj[4] = { b4.x, b4.y, b4.z, b4.w }, scj[4] = { sc4.x, sc4.y, sc4.z, sc4.w }, sfj[4] = { sf4.x, sf4.y, sf4.z, sf4.w };
+                    srt_d1h4 rv[2], av[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int nr = 0; nr < 2; ++nr) {
+                            const float v = acc[mt][nr][4 * k + j] + bj[j];
+                            rv[nr][j] = (_Float16)v;
+                            av[nr][j] = (_Float16)srt_enc_input1(v, scj[j], sfj[j], ap);
+                        }
+                    }
+                    const u32x2 ra = __builtin_bit_cast(u32x2, rv[0]), rb = __builtin_bit_cast(u32x2, rv[1]);
+                    const u32x2 aa = __builtin_bit_cast(u32x2, av[0]), ab = __builtin_bit_cast(u32x2, av[1]);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(ra.x, rb.x, false, false), r1 = __builtin_amdgcn_permlane32_swap(ra.y, rb.y, false, false);
+                    const auto a0 = __builtin_amdgcn_permlane32_swap(aa.x, ab.x, false, false), a1 = __builtin_amdgcn_permlane32_swap(aa.y, ab.y, false, false);
+                    *reinterpret_cast<u32x4*>(rawh + so) = (u32x4){ r0[0], r1[0], r0[1], r1[1] };
+                    *reinterpret_cast<u32x4*>(acth + so) = (u32x4){ a0[0], a1[0], a0[1], a1[1] };
+                }
+            }
+        }
+    }
+}
+// one launch for every stem of the call (up to six); the engine asks only where srt_down1_c8_ok holds
+int srt_launch_down1_f16(const SrtConvParams& p, hipStream_t s)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    if (p.Cin != 2 || p.Cout != 16 || p.stack < 1 || p.stack > 6 || !p.out16 || !p.c8out || !p.outAct || !p.bnScale || !p.bnShift || p.ws) return 1;
+    if (p.W % 4 || Wo % 64 || Ho % 8 || (size_t)p.stack * p.out_stem >= ((size_t)1 << 32) || (size_t)8 * p.H * p.W >= 0x7fffffffu) return 1;
+    const dim3 grid((unsigned)((Wo / 64) * p.ntiles));
+    if (p.stack <= 2) SRT_LAUNCH((srt_down1_f16_kernel<1>), grid, dim3(256), 0, s, p);
+    else if (p.stack <= 4) SRT_LAUNCH((srt_down1_f16_kernel<2>), grid, dim3(256), 0, s, p);
+    else SRT_LAUNCH((srt_down1_f16_kernel<3>), grid, dim3(256), 0, s, p);
+    return srt_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------- decoder v2
 // CLASSSTACK (Cout == 16): M tile = (px, co); accumulators per py only; 15 tap-MFMAs (ky x dx) per channel pair.
 template <int BM, int WM, int SW, int NSX, int NSY, int NI, int KC, bool CLASSSTACK, int ABL = 0, bool SPLITK = false, bool DUAL = false>

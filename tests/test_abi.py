@@ -207,6 +207,35 @@ def test_down1_stream_store_count_matches_its_vmcnt_wait(tmp_path):
         assert len(dma) >= 3                                                               # the LDS-DMA pieces the wait is about
 
 
+def test_down1_f16_store_count_matches_its_vmcnt_wait(tmp_path):
+    """srt_down1_f16_kernel (down1 of the fp16 mode on the fp16 MFMA, csrc/srt_nn2.hip) uses the streamed kernel's counted wait: s_waitcnt vmcnt(4 x stems) at the top of an
+    interval = "my DMA pieces have landed, the interval's stores may still fly".  Pinned on the ISA of the three instantiations (one, two, three M tiles): exactly two 16-byte
+    stores (raw, act) per (stem, channel group) = 8 per M tile, nothing in scratch, every counted immediate 4 .. 24 present, the LDS-DMA pieces and 10 fp16 MFMAs per M tile."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "spleeterrt_amd", "csrc")
+    asm = tmp_path / "nn2.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "srt_nn2.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = asm.read_text().split("\n")
+    for mt in (1, 2, 3):
+        mangled = "_Z20srt_down1_f16_kernelILi%dEEv13SrtConvParams" % mt
+        start = next(i for i, l in enumerate(txt) if l.startswith(mangled + ":"))
+        end = next(i for i in range(start, len(txt)) if txt[i].startswith("\t.end_amdhsa_kernel"))
+        body = [l.strip() for l in txt[start:end] if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
+        meta = [l for l in txt[start:end] if ".amdhsa_private_segment_fixed_size" in l]
+        assert meta and meta[0].split()[-1] == "0", meta
+        assert not [l for l in body if l.startswith("scratch_")]
+        stores = [l.split()[0] for l in body if l.startswith("global_store") or l.startswith("buffer_store")]
+        assert stores == ["global_store_dwordx4"] * (8 * mt), (mt, stores)
+        waits = set(int(m) for l in body if l.startswith("s_waitcnt") for m in re.findall(r"vmcnt\((\d+)\)", l))
+        assert {4, 8, 12, 16, 20, 24} <= waits, (mt, sorted(waits))
+        assert len([l for l in body if l.startswith("buffer_load_dwordx4") and " lds" in l]) >= 3
+        assert len([l for l in body if l.startswith("v_mfma_f32_32x32x16_f16")]) == 10 * mt
+
+
 def test_c8_kernels_store_count_matches_their_vmcnt_wait(tmp_path):
     """The C8-form fp16 kernels (csrc/srt_nn5.hip) prove "my LDS-DMA pieces of this step have landed" with s_waitcnt vmcnt(pieces still allowed in flight + NST), NST =
     the store instructions of the epilogue a wave issued behind the previous step's DMA (vmcnt retires in issue order).  An NST above the real count would let

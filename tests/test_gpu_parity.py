@@ -4,6 +4,8 @@ Tolerances (fp32 path, BASELINE.md §4 / SURVEY §8d): mask max-abs <= 2e-4 with
 (<= 1e-3 for the LUT flavour, whose table has a 9e-4 step at |x| = 7), stems rel-RMS <= 1e-4 and
 max-abs <= 1e-4 * peak.  Intermediate tensors are checked relative to their own RMS.
 """
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -50,6 +52,23 @@ def _check_taps(eng, oracle, coeff, x_tile, mode, s, t, masks=None, tag=""):
         d = float(np.abs(masks[s, t] - y).max())
         assert d <= MASK_TOL_EXACT, "%s mask stem %d tile %d: max abs %g" % (tag, s, t, d)
     return worst_r, worst_m
+
+
+@contextlib.contextmanager
+def _env(**kv):
+    """environment switches the engine reads per forward, restored on exit"""
+    import os
+    old = {k: os.environ.get(k) for k in kv}
+    try:
+        for k, v in kv.items():
+            os.environ[k] = str(v)
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _layer_kernels(eng, xd):
@@ -217,6 +236,8 @@ def test_down1_streamed_two_wave_form(oracle, coeffs, T, F, ntiles, stems, preci
     last = stems - 1                                             # the stem(s) of the remainder group
     picks = [(last, t) for t in sorted({0, ntiles // 2, ntiles - 1})]
     old = os.environ.get("SPLEETERRT_D1S2")
+    old_f16 = os.environ.get("SPLEETERRT_D1F16")
+    os.environ["SPLEETERRT_D1F16"] = "0"                         # (fp16 mode: the fp32-MFMA streamed kernels this test is about, not srt_down1_f16_kernel)
     try:
         os.environ["SPLEETERRT_D1S2"] = "0"
         m0 = eng.forward(xd).cpu().numpy().copy()
@@ -236,12 +257,73 @@ def test_down1_streamed_two_wave_form(oracle, coeffs, T, F, ntiles, stems, preci
             os.environ.pop("SPLEETERRT_D1S2", None)
         else:
             os.environ["SPLEETERRT_D1S2"] = old
+        if old_f16 is None:
+            os.environ.pop("SPLEETERRT_D1F16", None)
+        else:
+            os.environ["SPLEETERRT_D1F16"] = old_f16
     tol = 2e-2 if precision == "f16" else MASK_TOL_EXACT
     for s, t in picks:
         y = oracle.forward(coeffs(s), x[t], modes[s], oracle.VARIANT_VST)
         assert float(np.abs(m1[s, t] - y).max()) <= tol, (s, t)
     if precision == "f32":
         _check_taps(eng, oracle, coeffs(last), x[picks[1][1]], modes[last], last, picks[1][1], m1, "down1 two-wave")
+    eng.close()
+
+
+@pytest.mark.parametrize("T,F,ntiles,modes", [
+    (64, 512, 96, (1, 0, 1, 0, 1)),        # BASELINE configs[4]'s five stems in ONE launch: three M tiles, the last half empty; 4 columns x 96 tiles, 8 intervals; both activations
+    (128, 256, 192, (0, 1, 1)),            # three stems: two M tiles; 2 columns x 192 tiles, 16 intervals
+    (64, 512, 97, (1,)),                   # one stem: half an M tile (4 stores per wave and interval), odd tile count
+    (64, 1024, 48, (0, 1, 0, 1, 0, 1)),    # six stems: three full M tiles (24 stores per interval, the largest counted wait); 8 columns
+])
+def test_down1_fp16_mfma_form(oracle, coeffs, T, F, ntiles, modes):
+    """Round 6: in the fp16 mode down1 runs on v_mfma_f32_32x32x16_f16 like every other conv layer (srt_down1_f16_kernel, csrc/srt_nn2.hip: k-group = the five taps of one
+    (channel, ky) + three zero weights, every stem of the call in one launch, C8 outputs).  Not the fp32-MFMA chain: the magnitudes are rounded to halves first.  Checked:
+    the engine names the kernel; conv1 of EVERY stem on the first, an interior and the last tile against the fp32 oracle convolution (<= 2 / 1024 of the tensor's peak:
+    the input rounding + the output rounding) and against the fp32-MFMA streamed kernels (SPLEETERRT_D1F16=0) at the same bound; the act1 copy down2 reads against that
+    form too; no value of the tiles is left unwritten (whole-tensor compare, NaN-filled first); masks within the mode's 2e-2 of the fp32 oracle."""
+    import torch
+    import spleeterrt_amd as srt
+    stems = len(modes)
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=srt.VARIANT_VST, max_tiles=ntiles, precision=srt.PREC_F16)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    cf = coeffs
+    x = _mag_input(oracle, ntiles, T, F, seed=9100 + T + F + stems)
+    xd = torch.from_numpy(x).cuda()
+    picks = sorted({0, ntiles // 2, ntiles - 1})
+    with _env(SPLEETERRT_D1F16=0):
+        m0 = eng.forward(xd).cpu().numpy().copy()
+        k0 = _layer_kernels(eng, xd)
+        assert "srt_down1_stream_kernel<0, true" in k0["down1"], k0["down1"]
+        ref = {(n, s, t): eng.tensor(n, s, t) for s in range(stems) for t in picks for n in ("conv1", "act1")}
+    with _env(SPLEETERRT_D1F16=1):
+        m1 = eng.forward(xd).cpu().numpy()
+        k1 = _layer_kernels(eng, xd)
+        assert k1["down1"].startswith("srt_down1_f16_kernel<%d>" % ((stems + 1) // 2)), k1["down1"]
+        assert k1["down2"].startswith("srt_enc_c8<"), k1["down2"]
+        got = {k: eng.tensor(*k) for k in ref}
+    lo = oracle.layout()
+    worst = [0.0, 0.0, 0.0]
+    for (n, s, t), g in got.items():
+        want = ref[(n, s, t)]
+        assert g.shape == want.shape and np.isfinite(g).all(), (n, s, t)
+        e = float(np.abs(g - want).max() / np.abs(want).max())
+        worst[0 if n == "conv1" else 1] = max(worst[0 if n == "conv1" else 1], e)
+        assert e <= 2.0 / 1024, (n, s, t, e)
+        if n == "conv1":
+            c = cf(s)
+            w = c[lo.down[0].w:lo.down[0].w + 25 * 2 * 16]
+            o = oracle.conv5x5_s2(x[t], w, 16) + c[lo.down[0].b:lo.down[0].b + 16][:, None, None]
+            e2 = float(np.abs(g - o).max() / np.abs(o).max())
+            worst[2] = max(worst[2], e2)
+            assert e2 <= 2.0 / 1024, (s, t, e2)
+    for s in range(stems):
+        for t in picks:
+            y = oracle.forward(cf(s), x[t], modes[s], oracle.VARIANT_VST)
+            assert float(np.abs(m1[s, t] - y).max()) <= 2e-2, (s, t)
+            assert float(np.abs(m0[s, t] - y).max()) <= 2e-2, (s, t)
+    print("down1 on the fp16 MFMA %dx%d x%d x%d stems: conv1 / act1 vs the fp32-MFMA form %.3g / %.3g of the peak, conv1 vs the oracle %.3g" % (T, F, ntiles, stems, worst[0], worst[1], worst[2]))
     eng.close()
 
 
@@ -1244,6 +1326,13 @@ def test_down1_streamed_form(oracle, coeffs, T, F, ntiles, stems, prec):
         eng.set_coeff(s, coeffs(s))
     x = _mag_input(oracle, ntiles, T, F, seed=4100 + F + ntiles)
     xd = torch.from_numpy(x).cuda()
+    with _env(SPLEETERRT_D1F16=0):                              # (fp16 mode: the fp32-MFMA streamed kernel with halves stored; srt_down1_f16_kernel has its own test)
+        _down1_streamed_form_body(oracle, coeffs, eng, x, xd, T, F, ntiles, stems, f16)
+    eng.close()
+
+
+def _down1_streamed_form_body(oracle, coeffs, eng, x, xd, T, F, ntiles, stems, f16):
+    import torch
     eng.forward(xd)
     got = {(s, t): eng.tensor("conv1", s, t) for s in range(stems) for t in (0, ntiles // 2 + 1, ntiles - 1)}
     # conv2: in the fp16 mode it pins the act(BN(.)) halves the kernel writes beside conv1 (what down2 reads), and the batch runs down2 with four tiles per
@@ -1273,4 +1362,3 @@ def test_down1_streamed_form(oracle, coeffs, T, F, ntiles, stems, prec):
         for s in range(stems):
             assert np.array_equal(eng.tensor("conv1", s, 0), got[(s, t)]), (s, t)
             assert np.array_equal(eng.tensor("conv2", s, 0), gact[(s, t)]), (s, t)
-    eng.close()
