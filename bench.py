@@ -90,7 +90,7 @@ def mfma_peak(symbol):
     return PEAK_F16_MFMA_TFLOPS if is_f16_kernel(symbol) else PEAK_F32_MFMA_TFLOPS
 
 
-def layer_bytes(name, precision, act16, stems=STEMS):
+def layer_bytes(name, precision, act16, stems=STEMS, masks16=False):
     """ALGORITHMIC HBM bytes of one layer per instance (tile x stem): its input(s) read once, its output(s) written once, at the element size
     the tensors have in this mode (fp16 storage: raw_i, act_i and up_1..5 are halves; the encoder writes raw AND the act(BN(.)) copy).  Weights
     are read once per launch, not per instance, and are left out (<= 13 MB against GBs)."""
@@ -107,7 +107,7 @@ def layer_bytes(name, precision, act16, stems=STEMS):
         ci, co = _dec[i]
         hin = (T >> (6 - i)) * (F >> (6 - i))
         return ci * hin * e + co * 4 * hin * (4 if i == 5 else e)                 # up6's output (the head's input) stays fp32
-    return T * F * 4 + 2 * T * F * 4                                              # head: one plane in, two masks out
+    return T * F * 4 + 2 * T * F * (2 if masks16 else 4)                          # head: one plane in, two masks out (halves in the fp16 mode's srtSeparate: the engine's own buffer)
 
 
 # written by scripts/summarize_profiles.py from separate --pmc passes of this same command (latest round first); per precision
@@ -229,6 +229,8 @@ def make_line(a, rec):
     # FLOPs the matrix pipe EXECUTES in one step: the Winograd-form layers issue 0.49 of their algorithmic products
     prec = a.precision
     act16 = prec == "f16" and F % 256 == 0                # fp16 activation storage (csrc/srt_engine.hip: act16)
+    masks16 = layer_kernel.get("up7", "").replace(" ", "").endswith(",4,true>")      # the head wrote the engine's own mask buffer as halves (fp16 mode, csrc/srt_engine.hip: separate_issue)
+    mask_pcm_kb = 8.0 + (4.0 if masks16 else 8.0)         # per stem and frame: 8 KB of PCM out + 2 x 1024 mask values in
     nn_exec_flop = sum(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) for k in avg if k in LAYER_FLOP)
     # the step's MFMA time budget: every layer's executed FLOPs at the peak of the MFMA it runs on (fp16 modes mix both pipes)
     nn_peak_ms = sum(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) / (mfma_peak(layer_kernel.get(k, k)) * 1e12) * 1e3 for k in avg if k in LAYER_FLOP)
@@ -240,7 +242,7 @@ def make_line(a, rec):
     dom_tflops = dom_alg_tflops * dom_exec                # what the matrix pipe executes: the roofline figure
     dom_peak = mfma_peak(dom)
     dom_layers = sorted(k for k in avg if layer_kernel.get(k) == dom)
-    dom_bytes = sum(layer_bytes(k, prec, act16, stems) for k in dom_layers) * inst / len(dom_layers)      # algorithmic HBM bytes per launch
+    dom_bytes = sum(layer_bytes(k, prec, act16, stems, masks16) for k in dom_layers) * inst / len(dom_layers)      # algorithmic HBM bytes per launch
     dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
     # traffic / mfma_busy come from the committed counter passes (profiles/), NOT from this run: they are attached only when the profile is of
     # the SAME kernel symbol at the same launch shape and its launch duration agrees with this run's within 10 %; otherwise they are null and
@@ -323,14 +325,14 @@ def make_line(a, rec):
         # the HBM-bound stages against the same guide's 8 TB/s: algorithmic bytes per frame / measured kernel time
         "dsp_stages": {name: {"bound": "hbm", "achieved": kb * 1024.0 * rows / (avg[name] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": kb * 1024.0 * rows / (avg[name] * 1e-3) / 8e12, "algorithmic_kb_per_frame": kb}
-                       for name, kb in (("stft", 48.8), ("istft", 32.8 + stems * 16.0)) if name in avg},
+                       for name, kb in (("stft", 48.8), ("istft", 32.8 + stems * mask_pcm_kb)) if name in avg},
         "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
         "layer_kernels": {k: layer_kernel[k] for k in sorted(layer_kernel)},
         "layer_tflops": {k: round(LAYER_FLOP[k] * inst / (avg[k] * 1e-3) / 1e12, 2) for k in avg if k in LAYER_FLOP},     # algorithmic
         "layer_executed_frac": {k: round(LAYER_FLOP[k] * inst * executed_fraction(layer_kernel.get(k, k), prec) / (avg[k] * 1e-3) / 1e12 / mfma_peak(layer_kernel.get(k, k)), 4)
                                 for k in avg if k in LAYER_FLOP},
         # every layer against the HBM roofline too (algorithmic bytes at this mode's element sizes / kernel time / 8 TB/s)
-        "layer_hbm_frac": {k: round(layer_bytes(k, prec, act16, stems) * inst / (avg[k] * 1e-3) / (PEAK_HBM_TBS * 1e12), 4) for k in avg if k in LAYER_FLOP},
+        "layer_hbm_frac": {k: round(layer_bytes(k, prec, act16, stems, masks16) * inst / (avg[k] * 1e-3) / (PEAK_HBM_TBS * 1e12), 4) for k in avg if k in LAYER_FLOP},
     }
     rf = res["roofline"]
     if rf["hbm"]["frac"] > rf["frac"]:
@@ -339,7 +341,7 @@ def make_line(a, rec):
         rf["mfma"] = {k: rf[k] for k in ("achieved", "peak", "unit", "frac")}
         rf.update(bound="hbm", achieved=rf["hbm"]["achieved"], peak=rf["hbm"]["peak"], unit="GB/s", frac=rf["hbm"]["frac"])
     # the whole step against the HBM roofline: algorithmic bytes of every stage / ms_per_step
-    step_bytes = sum(layer_bytes(k, prec, act16, stems) for k in avg if k in LAYER_FLOP) * inst + (48.8 + 32.8 + stems * 16.0) * 1024.0 * rows
+    step_bytes = sum(layer_bytes(k, prec, act16, stems, masks16) for k in avg if k in LAYER_FLOP) * inst + (48.8 + 32.8 + stems * mask_pcm_kb) * 1024.0 * rows
     rf["step"]["hbm"] = {"achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": step_bytes / (step_ms * 1e-3) / (PEAK_HBM_TBS * 1e12),
                          "algorithmic_bytes": step_bytes}
     for where, v in (("roofline", rf["frac"]), ("roofline.hbm", rf["hbm"]["frac"]), ("step", rf["step"]["frac"]), ("step.hbm", rf["step"]["hbm"]["frac"]), ("nn_stack", res["nn_stack"]["frac"])):

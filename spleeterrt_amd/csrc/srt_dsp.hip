@@ -469,7 +469,8 @@ __global__ void __launch_bounds__(256, 3) srt_stft_kernel(const SrtStftParams p,
 }
 
 // NM: mask rows cover bins < F <= 256 NM, so only the first NM of a thread's eight bins can carry a mask value (F = 1024: 4 prefetch registers per channel instead of 8)
-template <int NM, bool RATIO = false>
+// M16: the masks are halves (the engine's own mask buffer in the fp16 mode, written by srt_head_rows_kernel<.., true>; never with RATIO)
+template <int NM, bool RATIO = false, bool M16 = false>
 __global__ void __launch_bounds__(256, RATIO ? 2 : 3) srt_istft_ola3_kernel(const SrtIstftParams p, int G)
 {
     const int pos = srt_xcd_order(gridDim.x), stem = pos % p.nstems, run = pos / p.nstems;       // stem fastest: the stems of a run share the spectrum rows in L2
@@ -500,13 +501,19 @@ __global__ void __launch_bounds__(256, RATIO ? 2 : 3) srt_istft_ola3_kernel(cons
         const int tile = f / p.T, t = f % p.T;
         const cf* specL = spec + (size_t)f * SRT_SPEC_LD;
         const cf* specR = specL + p.spec_ch_stride;
-        const float* mL = has_mask ? p.masks + ((size_t)(stem * p.ntiles + tile) * 2) * tf + (size_t)t * p.F : p.tab.postWin;
+        const size_t mo = ((size_t)(stem * p.ntiles + tile) * 2) * tf + (size_t)t * p.F;
+        const float* mL = has_mask ? p.masks + mo : p.tab.postWin;
         const float* mR = has_mask ? mL + tf : p.tab.postWin;
+        const _Float16* hL = reinterpret_cast<const _Float16*>(p.masks) + mo;                   // (M16: the launcher checks that masks are given)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = tid + 256 * j;
             sl[j] = specL[k]; sr[j] = specR[k];
-            if (j < NM) { const int km = min(k, p.F - 1); gl[j] = mL[km]; gr[j] = mR[km]; }
+            if (j < NM) {
+                const int km = min(k, p.F - 1);
+                if constexpr (M16) { gl[j] = (float)hL[km]; gr[j] = (float)hL[tf + km]; }
+                else { gl[j] = mL[km]; gr[j] = mR[km]; }
+            }
         }
         sl8 = specL[2048]; sr8 = specR[2048];
     };
@@ -608,6 +615,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
     // runs of at least 13 segments so the 3-frame warm-up stays below ~25 % (64-tile batch, 4 stems: G = 65, 4.6 %).
     // three-per-CU form: ONE round of the 768 resident workgroups (64-tile batch, 4 stems: G = 86, warm-up 3.5 %; two rounds measured the same, 1024 / 2304
     // workgroups 6 % / 1 % slower); the two-per-CU form keeps its two rounds of 512
+    if (p.masks16 && (!p.masks || p.F > 1024 || (p.ratio && p.nstems > 1))) return -1;      // halves are read by the three-per-CU kernel only
     const int target = p.F > 1024 ? 1024 : 768;
     // (runs x stems must not exceed the resident workgroups: five stems at 768 / 5 = 153.6 runs would leave two workgroups for a second round)
     const int max_runs = target / p.nstems > 0 ? target / p.nstems : 1;
@@ -621,6 +629,7 @@ int srt_launch_istft(const SrtIstftParams& p, hipStream_t s)
         if (p.F > 1024) SRT_LAUNCH((srt_istft_ola_kernel<true>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
         else SRT_LAUNCH((srt_istft_ola3_kernel<4, true>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     } else if (p.F > 1024) SRT_LAUNCH((srt_istft_ola_kernel<false>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
+    else if (p.masks16) SRT_LAUNCH((srt_istft_ola3_kernel<4, false, true>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     else SRT_LAUNCH((srt_istft_ola3_kernel<4>), dim3(blocks * p.nstems), dim3(256), 0, s, p, G);
     return srt_launch_status();
 }

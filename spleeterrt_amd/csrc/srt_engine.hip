@@ -118,6 +118,7 @@ struct srt_engine {
     uint16_t* wpack16cs_u5;                            // act16 only: up5's class-stacked fp16 weights [n_stems][4][15][2][32][8] (srt_nn5.hip)
     SrtConvParams up6_params; int up6_s0; unsigned up6_stale;          // the last forward ran up6 + head in one pass (no up6 plane stored): srtCopyTensor("up6") re-launches up6 alone from these
     bool last_c8_l1;                                   // ... and conv1 / act1 too (down1 ran on its streamed kernels)
+    bool masks16_req, last_masks16;                    // srtSeparate in the fp16 mode: the engine's OWN mask buffer may hold halves (asked for by separate_issue / what the last forward did)
     bool last_c8;                                      // the last forward stored raw2..6 / act2..5 / up1..4 channel-interleaved by eight (srt_nn5.hip): srtCopyTensor's view
     float* ws; size_t ws_floats;                       // split-K partial sums of small-batch launches (allocated on the first one)
     int graph_mode; unsigned long gclock; GraphSlot gslots[SRT_GRAPH_SLOTS];
@@ -213,7 +214,7 @@ int srtCreate(const srt_config* cfg, void* stream, srt_engine** out)
     memset(e->wpack16_down, 0, sizeof e->wpack16_down); memset(e->wpack16_up, 0, sizeof e->wpack16_up);
     memset(e->wino_u, 0, sizeof e->wino_u); memset(e->wino_u_stem, 0, sizeof e->wino_u_stem);
     memset(e->wino_e, 0, sizeof e->wino_e); memset(e->wino_e_stem, 0, sizeof e->wino_e_stem); memset(e->act32, 0, sizeof e->act32);
-    e->wpack16cs_u5 = nullptr; e->last_c8 = false; e->last_c8_l1 = false; e->up6_stale = 0; e->up6_s0 = 0;
+    e->wpack16cs_u5 = nullptr; e->last_c8 = false; e->last_c8_l1 = false; e->masks16_req = e->last_masks16 = false; e->up6_stale = 0; e->up6_s0 = 0;
     e->coeff_all = nullptr; e->wpack2_d1 = e->wpack2_u5 = nullptr; memset(e->wpack_down, 0, sizeof e->wpack_down); memset(e->wpack_up, 0, sizeof e->wpack_up);
     memset(e->have_coeff, 0, sizeof e->have_coeff);
     memset(e->raw, 0, sizeof e->raw); memset(e->up, 0, sizeof e->up); memset(e->act16buf, 0, sizeof e->act16buf);
@@ -479,7 +480,7 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
     // ... and down1's two outputs (raw1: up6's skip input, act1: down2's input) where down1 runs on its streamed kernels (SPLEETERRT_C8L1=0: planar, for A/B runs)
     const char* c8l1v = getenv("SPLEETERRT_C8L1");
     const bool c8_l1 = c8 && !(c8l1v && c8l1v[0] == '0') && e->cfg.impl == SRT_IMPL_MFMA && srt_down1_c8_ok(T, F, ntiles, (size_t)ntiles * e->raw_tile[0]);
-    e->last_c8 = c8; e->last_c8_l1 = c8_l1;
+    e->last_c8 = c8; e->last_c8_l1 = c8_l1; e->last_masks16 = false;
     {
         // all stems go in one launch per layer; the activation pair is per stem (spleeter.c:130-139) and travels as a bit mask
         unsigned elu_mask = 0;
@@ -616,6 +617,8 @@ static int forward_range(srt_engine* e, const float* d_mag, int ntiles, float* d
         head.w = cbase + e->lo.head_w; head.bias = cbase + e->lo.head_b; head.coeff_stem = SRT_COEFF_STRIDE;
         head.out = d_masks + (size_t)s0 * ntiles * 2 * HW; head.out_stem = (size_t)ntiles * 2 * HW; head.out_tile = 2 * HW;
         head.variant = e->cfg.variant;
+        head.out16 = e->masks16_req && d_masks == e->masks && srt_head_out16_ok(head);
+        e->last_masks16 = head.out16 != 0;
         bool head_done = false;
         for (int i = 0; i < 6; ++i) {                                           // decoder (spleeter.c:239-294)
             const LayerOff& L = e->lo.up[i];
@@ -760,10 +763,10 @@ int srtStft(srt_engine* e, const float* d_L, const float* d_R, size_t n, float* 
     return srtStftEx(e, d_L, d_R, n, srtStftFrames(n), srtStftRows(n), d_spec, d_mag);
 }
 
-static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio);
+static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio, bool masks16 = false);
 // (the public entry applies the masks as they are given: srtRatioMask is its caller's business)
 int srtIstft(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out) { return istft_issue(e, d_spec, rows, d_masks, d_out, false); }
-static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio)
+static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const float* d_masks, float* d_out, bool ratio, bool masks16)
 {
     if (!e || !d_spec || !d_out) return fail(-1, "srtIstft: null argument");
     DeviceScope ds(e->device);
@@ -776,6 +779,7 @@ static int istft_issue(srt_engine* e, const float* d_spec, size_t rows, const fl
     p.T = T; p.F = e->cfg.F;
     for (int s = 0; s < SRT_MAX_STEMS; ++s) p.oob[s] = e->cfg.oob_weight[s];
     p.ratio = ratio ? 1 : 0;
+    p.masks16 = masks16 ? 1 : 0;
     p.frames_out = nullptr; p.out = d_out; p.out_len = srtIstftLength(rows); p.tab = tables_of(e);
     TimerScope ts(e, "istft");
     if (srt_launch_istft(p, e->stream)) return fail(-2, "istft launch failed");
@@ -788,10 +792,15 @@ static int separate_issue(srt_engine* e, const float* d_L, const float* d_R, siz
     const size_t ntiles = (rows + T - 1) / T;
     int rc = srtStftEx(e, d_L, d_R, n, frames, rows, (float*)e->spec, e->mag);
     if (rc) return rc;
+    // fp16 mode: the masks between the head and the inverse transform - the engine's own buffer, never seen by a caller - are halves where both kernels take them
+    // (srt_head_rows_kernel<.., true> / srt_istft_ola3_kernel<.., true>: F <= 1024, no ratio mask, head launches of >= 1024 workgroups; SPLEETERRT_M16=0: floats, for A/B runs)
+    const char* m16v = getenv("SPLEETERRT_M16");
+    e->masks16_req = e->cfg.precision == SRT_PREC_F16 && e->act16 && !e->cfg.ratio_mask && e->cfg.F <= 1024 && !(m16v && m16v[0] == '0');
     rc = forward_range(e, e->mag, (int)ntiles, e->masks, 0, e->cfg.n_stems);
+    e->masks16_req = false;
     if (rc) return rc;
     // ratio_mask: normalised across the stems inside the inverse kernel's prologue (srt_ratio_of, srt_dsp.hip) - e->masks keeps the raw sigmoid masks
-    return istft_issue(e, (const float*)e->spec, rows, e->masks, d_out, e->cfg.ratio_mask != 0);
+    return istft_issue(e, (const float*)e->spec, rows, e->masks, d_out, e->cfg.ratio_mask != 0, e->last_masks16);
 }
 
 int srtSeparateEx(srt_engine* e, const float* d_L, const float* d_R, size_t n, size_t frames, size_t rows, float* d_out)

@@ -96,7 +96,10 @@ struct SrtHeadParams {    // up7: 4x4 dilation-2 conv 1->2 channels + bias + sig
     const float* w; const float* bias; size_t coeff_stem;
     float* out; size_t out_stem, out_tile;    // [2][H][W] per instance
     int variant;
+    int out16;            // the two mask planes leave as IEEE halves (same layout, strides in elements): the engine's own mask buffer between the network and the inverse
+                          // transform of srtSeparate in the fp16 mode (srt_head_out16_ok); the masks srtForward hands to its caller are always floats
 };
+int  srt_head_out16_ok(const SrtHeadParams& p);      // the launch runs on srt_head_rows_kernel<.., 4, true>
 
 // launchers (srt_nn.hip)
 int  srt_launch_enc(const SrtConvParams& p, int impl, hipStream_t s);
@@ -157,6 +160,7 @@ struct SrtIstftParams {
     const float2* spec; size_t spec_ch_stride;
     int frames;               // rows to synthesise
     const float* masks;       // [nstems][ntiles][2][T][F] or nullptr (all-ones)
+    int masks16;              // the masks are halves (srt_istft_ola3_kernel<.., M16>: F <= 1024, no ratio); see SrtHeadParams::out16
     int nstems, ntiles, T, F;
     float oob[SRT_MAX_STEMS];
     int ratio;                // 1: masks are normalised across the stems while they are applied, m_s^2 / sum_j m_j^2 (srt_config.ratio_mask; needs masks of ALL nstems)

@@ -596,7 +596,8 @@ __global__ void __launch_bounds__(256, 2) srt_dec_mfma(const SrtConvParams p)
 // other parity, so NRO of them share all but three of their input rows: 3 (NRO + 3) float4 loads per NRO output quads instead of 12 NRO - for
 // NRO = 4, 5.25 instead of 12 per quad.  The layer is 0.8 GB of HBM traffic; what it was short of is load issue, not bytes.  Per output the taps
 // accumulate in the order of the kernel above (ky, then kx): identical results.
-template <bool LUT, int NRO>
+// O16: the masks leave as halves (8-byte stores): the engine's own mask buffer in the fp16 mode (SrtHeadParams::out16); same values, rounded once
+template <bool LUT, int NRO, bool O16 = false>
 __global__ void __launch_bounds__(256) srt_head_rows_kernel(const SrtHeadParams p)
 {
     const int W4 = p.W >> 2, nsets = 2 * ((p.H + 2 * NRO - 1) / (2 * NRO));
@@ -656,8 +657,16 @@ __global__ void __launch_bounds__(256) srt_head_rows_kernel(const SrtHeadParams 
                 o0.x = srt_sigmoid_fast(a[j][0].x + b0); o0.y = srt_sigmoid_fast(a[j][1].x + b0); o0.z = srt_sigmoid_fast(a[j][2].x + b0); o0.w = srt_sigmoid_fast(a[j][3].x + b0);
                 o1.x = srt_sigmoid_fast(a[j][0].y + b1); o1.y = srt_sigmoid_fast(a[j][1].y + b1); o1.z = srt_sigmoid_fast(a[j][2].y + b1); o1.w = srt_sigmoid_fast(a[j][3].y + b1);
             }
-            *reinterpret_cast<float4*>(y + (size_t)h * p.W + w0) = o0;
-            *reinterpret_cast<float4*>(y + hw + (size_t)h * p.W + w0) = o1;
+            if constexpr (O16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                _Float16* yh = reinterpret_cast<_Float16*>(p.out) + stem * p.out_stem + tile * p.out_tile;
+                const h4 q0 = { (_Float16)o0.x, (_Float16)o0.y, (_Float16)o0.z, (_Float16)o0.w }, q1 = { (_Float16)o1.x, (_Float16)o1.y, (_Float16)o1.z, (_Float16)o1.w };
+                *reinterpret_cast<h4*>(yh + (size_t)h * p.W + w0) = q0;
+                *reinterpret_cast<h4*>(yh + hw + (size_t)h * p.W + w0) = q1;
+            } else {
+                *reinterpret_cast<float4*>(y + (size_t)h * p.W + w0) = o0;
+                *reinterpret_cast<float4*>(y + hw + (size_t)h * p.W + w0) = o1;
+            }
         }
     }
 }
@@ -1306,7 +1315,7 @@ int srt_launch_up6_head(const SrtConvParams& p, const SrtHeadParams& h, hipStrea
     const char* fv = getenv("SPLEETERRT_FUSE_HEAD");                          // (read per launch: the parity tests switch it inside one process)
     const int mode = fv && fv[0] ? atoi(fv) : -1;
     if (mode == 0 || (mode < 0 && !SRT_FUSE_HEAD_DEFAULT(p.in16))) return 1;
-    if (p.Cout != 1 || p.Cin != 32 || p.CA != 16 || p.out16 || !p.srcA || !p.srcB || (p.H & 1) || p.W % (p.in16 ? 8 : 4)) return 1;
+    if (p.Cout != 1 || p.Cin != 32 || p.CA != 16 || p.out16 || h.out16 || !p.srcA || !p.srcB || (p.H & 1) || p.W % (p.in16 ? 8 : 4)) return 1;
     // up5's output in C8 (large fp16-storage batches, srt_nn5.hip): not covered.  A BC8 instantiation of this kernel (the same three edits as in srt_up6_stream_kernel) was
     // built and dropped: its masks differed from run to run in 16-lane pieces of single rows (first / last interval of the head, channel 0) while the planar form and the
     // BC8 form of the two-kernel path are stable - unexplained, and this form is slower anyway.
@@ -1319,12 +1328,25 @@ int srt_launch_up6_head(const SrtConvParams& p, const SrtHeadParams& h, hipStrea
     return srt_launch_status();
 }
 
-int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
-{
 #ifndef SRT_HEAD_ROWS_DEFAULT
 #define SRT_HEAD_ROWS_DEFAULT 4
 #endif
+int srt_head_out16_ok(const SrtHeadParams& p)
+{
+    return SRT_HEAD_ROWS_DEFAULT == 4 && p.W % 4 == 0 && (size_t)p.H * (p.W / 4) * p.nstems * p.ntiles >= (size_t)256 * 1024 * 4;
+}
+int srt_launch_head(const SrtHeadParams& p, hipStream_t s)
+{
     int nro = SRT_HEAD_ROWS_DEFAULT;
+    if (p.out16) {
+        if (!srt_head_out16_ok(p)) return -1;
+        const size_t nsets = 2 * (size_t)((p.H + 7) / 8);
+        size_t bx = (nsets * (p.W / 4) + 255) / 256;
+        if (bx > 65535) bx = 65535;
+        const unsigned grid = (unsigned)bx * p.nstems * p.ntiles;
+        if (p.variant == 0) SRT_LAUNCH((srt_head_rows_kernel<true, 4, true>), dim3(grid), dim3(256), 0, s, p); else SRT_LAUNCH((srt_head_rows_kernel<false, 4, true>), dim3(grid), dim3(256), 0, s, p);
+        return srt_launch_status();
+    }
 #ifdef SRT_TUNING
     if (const char* tv = getenv("SRT_TUNE_HEADROWS")) nro = atoi(tv);         // 0: one output row per thread (srt_head_kernel4), 2, 4
 #endif

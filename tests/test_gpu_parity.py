@@ -875,6 +875,57 @@ def test_config4_five_stems_fp16_end_to_end(oracle, coeffs, prec, mask_tol, stem
     eng.close()
 
 
+@pytest.mark.parametrize("T,F,ntiles,stems,variant", [(256, 1024, 8, 2, "vst"), (64, 512, 33, 5, "lut"), (128, 1024, 11, 3, "vst")])
+def test_fp16_mode_masks_as_halves_between_head_and_inverse(oracle, coeffs, T, F, ntiles, stems, variant):
+    """Round 6: in the fp16 mode srtSeparate keeps ITS OWN mask buffer (head -> inverse transform, never handed to a caller) as halves where the head launch is
+    large enough (srt_head_rows_kernel<.., 4, true> writes them, srt_istft_ola3_kernel<4, false, true> reads them): the same sigmoid values rounded once to 11 bits.
+    Checked: the engine names both kernels; the stems equal the float-mask form (SPLEETERRT_M16=0) within 1e-3 of their peak and 5e-4 rel-RMS (a mask in [0, 1] rounded to
+    a half is off by <= 2.5e-4 of itself); srtForward's masks - the caller's - stay floats and are untouched by the switch; a ratio-mask engine keeps float masks.
+    (The float-mask chain itself is held against the CPU oracle by the end-to-end tests; the signal ends in a tail tile.)"""
+    import torch
+    import spleeterrt_amd as srt
+    n = ntiles * T * 1024 - 3000                               # the last tile is a tail tile
+    L, R = oracle.synth_audio(n, 77 + T + stems, True)
+    modes = tuple((s + 1) % 2 for s in range(stems))
+    var = srt.VARIANT_VST if variant == "vst" else srt.VARIANT_EXE
+    eng = _engine(F=F, T=T, stem_modes=modes, variant=var, max_tiles=ntiles, precision=srt.PREC_F16)
+    for s in range(stems):
+        eng.set_coeff(s, coeffs(s))
+    Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+
+    def kernels():
+        eng.set_timing(True); eng.separate(Ld, Rd); ks = dict(eng.get_timing_kernels()); eng.set_timing(False)
+        return ks
+    with _env(SPLEETERRT_M16=0):
+        ref = eng.separate(Ld, Rd).cpu().numpy().copy()
+        k0 = kernels()
+    assert k0["up7"].startswith("srt_head_rows_kernel<") and not k0["up7"].rstrip("> ").endswith("true"), k0["up7"]
+    got = eng.separate(Ld, Rd).cpu().numpy()
+    k1 = kernels()
+    assert k1["up7"].startswith("srt_head_rows_kernel<") and k1["up7"].rstrip("> ").endswith(", 4, true"), k1["up7"]
+    assert k1["istft"].startswith("srt_istft_ola3_kernel<4, false, true"), k1["istft"]
+    assert np.isfinite(got).all()
+    for s in range(stems):
+        peak = float(np.abs(ref[s]).max())
+        assert float(np.abs(got[s] - ref[s]).max()) <= 1e-3 * peak, (s, float(np.abs(got[s] - ref[s]).max()) / peak)
+        assert _rel_rms(got[s], ref[s]) <= 5e-4, (s, _rel_rms(got[s], ref[s]))
+    # the caller's masks are floats whatever the engine does inside srtSeparate
+    spec, mag = eng.stft(Ld, Rd)
+    m_a = eng.forward(mag).cpu().numpy()
+    with _env(SPLEETERRT_M16=0):
+        m_b = eng.forward(mag).cpu().numpy()
+    assert m_a.dtype == np.float32 and np.array_equal(m_a, m_b)
+    out2 = eng.istft(spec, torch.from_numpy(m_a).cuda()).cpu().numpy()          # the public inverse on float masks = the float-mask chain
+    assert np.array_equal(out2, ref)
+    eng.close()
+    engr = _engine(F=F, T=T, stem_modes=modes, variant=var, max_tiles=ntiles, precision=srt.PREC_F16, ratio_mask=True)
+    for s in range(stems):
+        engr.set_coeff(s, coeffs(s))
+    engr.set_timing(True); engr.separate(Ld, Rd); kr = dict(engr.get_timing_kernels()); engr.set_timing(False)
+    assert not kr["up7"].rstrip("> ").endswith(", 4, true"), kr["up7"]
+    engr.close()
+
+
 @pytest.mark.parametrize("modes,ntiles,F", [((1, 0, 1, 1, 0), 2, 512), ((1, 0, 1, 1, 0, 1), 2, 512), ((1, 1, 0, 1, 1), 48, 1024)])
 def test_more_than_four_stems_down1_groups(oracle, coeffs, modes, ntiles, F):
     """Five and six sub-networks in fp32 (round 5): down1 goes out as stacked groups of four stems + the remainder (4 + 1, 4 + 2), each group with its own
