@@ -41,7 +41,8 @@ def find(table, sym):
 inst = b["config"]["stems"] * b["config"]["tiles_per_gpu"]
 rows_total = b["config"]["tiles_per_gpu"] * bench.T
 order = ["stft", "down1", "down2", "down3", "down4", "down5", "down6", "up1", "up2", "up3", "up4", "up5", "up6", "up7", "istft"]
-dsp_kb = {"stft": 48.8, "istft": 32.8 + b["config"]["stems"] * 16.0}
+masks16 = b["layer_kernels"].get("up7", "").replace(" ", "").endswith(",4,true>")     # fp16 mode: the engine's own mask buffer holds halves (bench.py counts the same)
+dsp_kb = {"stft": 48.8, "istft": 32.8 + b["config"]["stems"] * (12.0 if masks16 else 16.0)}
 print("Kernel table as of HEAD (%s; `%s`, %d tiles x %d stems of %dx%d, %s): step %.3f ms = %.0f x real-time, %.3f M frames/s.\n" % (
     tag, "profiles/%s" % bench_name, b["config"]["tiles_per_gpu"], b["config"]["stems"], bench.T, bench.F, b["dtype"], b["ms_per_step"], b["value"], b["frames_per_s"] / 1e6))
 print("| layer | kernel | ms | bound | executed frac of MFMA peak | algorithmic HBM frac | counter traffic / algorithmic bytes | MFMA busy | wait frac | LDS conflict cycles | VGPR / LDS KB / WG per CU-ish occ | spills (v / s) |")
@@ -61,14 +62,14 @@ for name in order:
         alg = dsp_kb[name] * 1024.0 * rows_total
         ex, hb, bound = "", "%.2f" % (alg / (ms * 1e-3) / 8e12), "HBM"
     else:
-        alg = bench.layer_bytes(name, prec, act16, b["config"]["stems"]) * inst
+        alg = bench.layer_bytes(name, prec, act16, b["config"]["stems"], masks16) * inst
         ex, hb = "%.2f" % b["layer_executed_frac"][name], "%.2f" % b["layer_hbm_frac"][name]
         bound = "HBM" if b["layer_hbm_frac"][name] > b["layer_executed_frac"][name] else "MFMA"
     tr = busy = wait = confl = ""
     if pm:
         if "hbm_read_bytes_per_launch" in pm and "hbm_write_bytes_per_launch" in pm:
             peers = groups.get(first, [name])                                # the counters are per kernel SYMBOL: averaged over the layers it ran
-            alg_avg = alg if name in dsp_kb else sum(bench.layer_bytes(k, prec, act16, b["config"]["stems"]) for k in peers) * inst / len(peers)
+            alg_avg = alg if name in dsp_kb else sum(bench.layer_bytes(k, prec, act16, b["config"]["stems"], masks16) for k in peers) * inst / len(peers)
             tr = "%.2f%s" % ((pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]) / alg_avg, " (avg of %s)" % "-".join([peers[0], peers[-1]]) if len(peers) > 1 else "")
         busy = "%.2f" % pm["mfma_busy_frac"] if pm.get("mfma_busy_frac") else ""
         wait = "%.2f" % pm["wait_any_frac"] if "wait_any_frac" in pm else ""

@@ -21,13 +21,49 @@ def short(n):
     return re.sub(r"^void |\((const )?Srt\w+Params.*$", "", n).strip()
 
 
-rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
-with open(os.path.join("profiles", tag + "_kernel_stats.csv"), "w") as f:
+# The engine's first launch of a C8 layer shape TIMES six workgroup-count candidates (c8_tuned, csrc/srt_nn5.hip): those launches carry the layer's kernel symbol and
+# would pull every per-launch average away from the step's.  The summaries therefore keep, per symbol, only the dispatches of the TIMED passes: the last
+# (layers of one step that run the symbol) x (passes) of the process - 5 passes for the kernel trace, 1 for each counter pass (scripts/profile_gpu*.sh).  The layer ->
+# symbol map is the one the traced run printed (bench_under_trace.json); symbols it does not name (weight packing, conversions) keep every dispatch.
+per_step = collections.Counter()
+try:
+    lk = json.load(open(os.path.join(src, "bench_under_trace.json")))["layer_kernels"]
+    for v in lk.values():
+        for sym in v.split(" + "):
+            per_step[sym.strip()] += 1
+except Exception as ex:
+    print("no bench_under_trace.json (%s): every dispatch counts" % ex)
+TRACE_PASSES, PMC_PASSES = 5, 1
+
+
+def timed(disp, k, passes):
+    """disp: list of (dispatch id, ...) of symbol k in any order -> the timed passes' share"""
+    disp = sorted(disp, key=lambda t: t[0])
+    n = per_step.get(k, 0) * passes
+    return disp[-n:] if 0 < n < len(disp) else disp
+
+
+raw = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+with open(os.path.join("profiles", tag + "_kernel_stats_raw.csv"), "w") as f:      # rocprofv3 --stats as it came (every dispatch of the process, tuning and warm-up included)
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-    for r in rows:
+    for r in raw:
         if "srt_" in r["Name"]:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+byk = collections.defaultdict(list)
+for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_trace.csv"))):
+    if "srt_" in r["Kernel_Name"]:
+        byk[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+stat = {}
+for k, disp in byk.items():
+    d = [x[1] for x in timed(disp, k, TRACE_PASSES)]
+    stat[k] = (len(d), sum(d), sum(d) / len(d), min(d), max(d), len(disp))
+tot = sum(v[1] for v in stat.values())
+with open(os.path.join("profiles", tag + "_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "DispatchesInProcess"])
+    for k, v in sorted(stat.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, v[0], v[1], "%.6f" % v[2], "%.2f" % (100.0 * v[1] / tot), v[3], v[4], v[5]])
 
 
 def pmc(sub):
@@ -37,10 +73,15 @@ def pmc(sub):
     dur = collections.defaultdict(float)
     if not os.path.exists(p):
         return agg, cnt, dur
-    for r in csv.DictReader(open(p)):
-        if "srt_" not in r["Kernel_Name"]:
-            continue
+    allrows = [r for r in csv.DictReader(open(p)) if "srt_" in r["Kernel_Name"]]
+    ids = collections.defaultdict(set)
+    for r in allrows:
+        ids[short(r["Kernel_Name"])].add(int(r["Dispatch_Id"]))
+    keep = {k: set(t[0] for t in timed([(i,) for i in v], k, PMC_PASSES)) for k, v in ids.items()}
+    for r in allrows:
         k = short(r["Kernel_Name"])
+        if int(r["Dispatch_Id"]) not in keep[k]:
+            continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in cnt[k]:
             cnt[k].add(r["Dispatch_Id"])
