@@ -134,6 +134,62 @@ int srt_launch_c8_to_float(const void* src, float* dst, int C, size_t hw, hipStr
     return srt_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------- operand prefetch distance of the tap loops
+// SRT_C8_PDE: taps the encoder's A / B fragment reads run ahead of their MFMAs; SRT_C8_PDA / SRT_C8_PDB: the decoder's A fragments (taps ahead) and B fragments
+// (input shifts ahead).  0 = the compiler's own order.  The group barriers take literal sizes, hence the switches (their argument is a constant once the tap loop is unrolled).
+#ifndef SRT_C8_PDE
+#define SRT_C8_PDE 3
+#endif
+#ifndef SRT_C8_PDA
+#define SRT_C8_PDA 3
+#endif
+#ifndef SRT_C8_PDB
+#define SRT_C8_PDB 1
+#endif
+__device__ __forceinline__ void c8_sgb_reads(int n)
+{
+    switch (n) {
+    case 1: __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); break;
+    case 2: __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); break;
+    case 3: __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); break;
+    case 4: __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); break;
+    default: break;
+    }
+}
+__device__ __forceinline__ void c8_sgb_mfma(int n)
+{
+    switch (n) {
+    case 1: __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); break;
+    case 2: __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); break;
+    default: break;
+    }
+}
+
+// the decoder's taps in shift-major order (the order of srt_dec_c8's reference loop): A-fragment row block, accumulator, input shift, first tap of its shift
+template <bool CS>
+struct C8DecOrder {
+    int aidx[25], acc[25], sh[25], first[25], n;
+    constexpr C8DecOrder() : aidx{}, acc{}, sh{}, first{}, n(0)
+    {
+        for (int s = 0; s < 9; ++s) {
+            const int dy = s / 3 - 1, dx = s % 3 - 1;
+            int f = 1;
+            for (int ky = 0; ky < 5; ++ky) {
+                const int py = (ky + 1) & 1;
+                if ((py + 1 - ky) / 2 != dy) continue;
+                if (CS) { aidx[n] = ky * 3 + dx + 1; acc[n] = py; sh[n] = s; first[n] = f; f = 0; ++n; }
+                else {
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int px = (kx + 1) & 1;
+                        if ((px + 1 - kx) / 2 != dx) continue;
+                        aidx[n] = ky * 5 + kx; acc[n] = py * 2 + px; sh[n] = s; first[n] = f; f = 0; ++n;
+                    }
+                }
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------- encoder, C8 in -> C8 out (raw + act)
 // Tile = TH x TW outputs of NI instances = 8 sub-tiles of 32 pixels (SW wide); M block = 32 output channels.
 // LDS patch of a stage: [k-group 2][NI][PH = 2 TH + 3 rows][even columns PWH | odd columns PWH] pixel slots of 16 B: the stride-2 taps of 32 neighbouring
@@ -318,7 +374,29 @@ __global__ void __launch_bounds__(512, 1) srt_enc_c8(const SrtConvParams p, int 
             }
             const _Float16* spatch = s_mem + (s & 1) * STAGE_H;
             const _Float16* sw = spatch + PATCH_H;
-            if (!(ABL & 4)) {
+            if constexpr (ABL == 0 && SRT_C8_PDE > 0) {
+                // Operand reads run PD taps ahead of the MFMAs that use them.  Left to itself the compiler issues a tap's two ds_read_b128 right in front of its MFMA
+                // (s_waitcnt lgkmcnt(1..2) before every one of the 25): a 32-cycle MFMA behind a ~130-cycle LDS round trip, with one other wave per SIMD to fill it.
+                // The sched_group_barrier pairs pin the order "reads of tap t + PD, then the MFMAs of tap t"; same MFMA chain, same results.
+                constexpr int PD = SRT_C8_PDE;
+                h8 af[PD + 1], bfr[PD + 1][NR];
+                auto ld = [&](int tap) __attribute__((always_inline)) {
+                    const int ky = tap / 5, kx = tap % 5, sl = tap % (PD + 1);
+                    const int koff = (ky * ROWS + ((kx + 1) & 1) * PWH + ((kx + 3) >> 1)) * 8;
+                    af[sl] = *reinterpret_cast<const h8*>(sw + tap * 512 + aoff);
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) bfr[sl][n] = *reinterpret_cast<const h8*>(spatch + boff[n] + koff);
+                };
+#pragma unroll
+                for (int t = 0; t < PD; ++t) { ld(t); c8_sgb_reads(1 + NR); }
+#pragma unroll
+                for (int tap = 0; tap < 25; ++tap) {
+                    if (tap + PD < 25) { ld(tap + PD); c8_sgb_reads(1 + NR); }
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % (PD + 1)], bfr[tap % (PD + 1)][n], acc[n], 0, 0, 0);
+                    c8_sgb_mfma(NR);
+                }
+            } else if (!(ABL & 4)) {
 #pragma unroll
                 for (int tap = 0; tap < 25; ++tap) {
                     const int ky = tap / 5, kx = tap % 5;
@@ -576,6 +654,32 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
             }
             const _Float16* spatch = s_mem + (s % ST) * STAGE_H;
             const _Float16* sw = spatch + PATCH_H;
+            if constexpr (ABL == 0 && SRT_C8_PDA > 0) {
+                // operand reads ahead of their MFMAs (see srt_enc_c8): A fragments PDA taps ahead, a shift's B fragments when the shift PDB before it starts; the flat tap
+                // order is the shift-major order of the loop below (C8DecOrder), so every accumulator sees the same MFMA chain
+                constexpr C8DecOrder<CS> O{};
+                static_assert(O.n == NT, "tap count");
+                constexpr int PDA = SRT_C8_PDA, PDB = SRT_C8_PDB > 0 ? SRT_C8_PDB : 1;
+                h8 af[PDA + 1], bfr[PDB + 1][NR];
+                auto lda = [&](int t) __attribute__((always_inline)) { af[t % (PDA + 1)] = *reinterpret_cast<const h8*>(sw + O.aidx[t] * 512 + aoff); };
+                auto ldb = [&](int sft) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) bfr[sft % (PDB + 1)][n] = *reinterpret_cast<const h8*>(spatch + boff[n] + ((sft / 3 - 1) * PC + (sft % 3 - 1)) * 8);
+                };
+#pragma unroll
+                for (int sft = 0; sft < PDB; ++sft) { ldb(sft); c8_sgb_reads(NR); }
+#pragma unroll
+                for (int t = 0; t < PDA; ++t) { lda(t); c8_sgb_reads(1); }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (O.first[t] && O.sh[t] + PDB < 9) { ldb(O.sh[t] + PDB); c8_sgb_reads(NR); }
+                    if (t + PDA < NT) { lda(t + PDA); c8_sgb_reads(1); }
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+                        acc[n][O.acc[t]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % (PDA + 1)], bfr[O.sh[t] % (PDB + 1)][n], acc[n][O.acc[t]], 0, 0, 0);
+                    c8_sgb_mfma(NR);
+                }
+            } else
 #pragma unroll
             for (int sh = 0; sh < ((ABL & 4) ? 0 : 9); ++sh) { // shift-major: one B fragment per sub-tile and input shift
                 const int dy = sh / 3 - 1, dx = sh % 3 - 1;
