@@ -33,7 +33,9 @@ extern "C" {
 #define SRT_IMPL_MFMA   0   /* MFMA implicit-GEMM kernels (product path) */
 #define SRT_IMPL_NAIVE  1   /* one-thread-per-output HIP kernels (debug cross-check, still GPU) */
 #define SRT_PREC_F32    0   /* v_mfma_f32_32x32x2_f32: exact fp32 products (default; the headline path) */
-#define SRT_PREC_F16    1   /* v_mfma_f32_32x32x16_f16, activations rounded to fp16 (BASELINE configs[4]; mask tolerance 2e-2) */
+#define SRT_PREC_F16    1   /* v_mfma_f32_32x32x16_f16, activations rounded to fp16 (BASELINE configs[4]; mask tolerance 2e-2).  Large batches: the network's input
+                             * magnitudes are rounded to halves too (saturating at 65504, ~60x what full-scale PCM gives), and srtSeparate keeps its own masks as halves;
+                             * STFT / iSTFT and every mask handed to a caller stay fp32 */
 #define SRT_PREC_F16X2  2   /* same MFMA, activations split hi+lo: products exact in fp32 BECAUSE the weights are fp16 values - srtSetCoeff* checks
                              * every conv weight of the blob and refuses (-5, srtLastError names the count) one that the fp16 pack would round, e.g. a raw
                              * fp32 .dat blob with 24-bit mantissas: nothing is rounded silently in this mode */

@@ -741,8 +741,11 @@ __global__ void __launch_bounds__(256, 2) srt_down1_f16_kernel(const SrtConvPara
             const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
             const float2 v2 = *reinterpret_cast<const float2*>(row + 8);
             srt_d1h8 b0, b1;                                                    // input columns 2 ox - 1 + kx of pixel ox = 2 l31 + nr: ring columns 4 l31 + 2 nr + 3 + kx
-            b0[0] = (_Float16)v0.w; b0[1] = (_Float16)v1.x; b0[2] = (_Float16)v1.y; b0[3] = (_Float16)v1.z; b0[4] = (_Float16)v1.w; b0[5] = b0[6] = b0[7] = (_Float16)0.0f;
-            b1[0] = b0[2]; b1[1] = b0[3]; b1[2] = b0[4]; b1[3] = (_Float16)v2.x; b1[4] = (_Float16)v2.y; b1[5] = b1[6] = b1[7] = (_Float16)0.0f;
+            // (magnitudes are >= 0; one beyond the largest half saturates instead of becoming inf - full-scale PCM gives ~1e3, so that is ~60x over)
+            constexpr float HMAX = 65504.0f;
+            b0[0] = (_Float16)fminf(v0.w, HMAX); b0[1] = (_Float16)fminf(v1.x, HMAX); b0[2] = (_Float16)fminf(v1.y, HMAX); b0[3] = (_Float16)fminf(v1.z, HMAX);
+            b0[4] = (_Float16)fminf(v1.w, HMAX); b0[5] = b0[6] = b0[7] = (_Float16)0.0f;
+            b1[0] = b0[2]; b1[1] = b0[3]; b1[2] = b0[4]; b1[3] = (_Float16)fminf(v2.x, HMAX); b1[4] = (_Float16)fminf(v2.y, HMAX); b1[5] = b1[6] = b1[7] = (_Float16)0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (ky == 0) {
