@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(512, WPE) srt_dec_c8(const SrtConvParams p, in
 // ------------------------------------------------------------------------------------------- dispatch
 #ifdef SRT_TUNING
 static int c8_abl() { const char* t = getenv("SRT_TUNE_C8"); return t ? atoi(t) : 0; }
-#define C8_ABL_CASES(X) X(3) X(4) X(8) X(16) X(12)
+#define C8_ABL_CASES(X) X(3) X(4) X(8) X(16) X(12) X(32)
 #endif
 static int c8_env(const char* name, int dflt)
 {
